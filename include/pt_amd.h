@@ -1,0 +1,328 @@
+/*
+ * pt_amd.h -- C ABI of the MI355X render-loop library (libptamd.so).
+ *
+ * The library replaces one block of the reference program: the OpenMP pixel
+ * loop of the final course step (reference src/15/pathtracer.cpp:199-221) and
+ * everything that loop calls (pathSample, BVH traversal, intersection,
+ * materials, textures, environment maps, camera ray generation).  Scene
+ * construction, OBJ import and image output stay in the caller.
+ *
+ * All structs are plain data; all pointers in a pt_scene_desc are host
+ * pointers that only have to stay valid for the duration of the call they
+ * are passed to.  Every function returns 0 on success and a negative
+ * pt_status on failure; pt_last_error() gives the message of the last
+ * failure on the calling thread.  Nothing in here aborts the process.
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1u
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad size, index out of range */
+    PT_ERR_UNSUPPORTED = -2,      /* a dynamic type outside the closed set below */
+    PT_ERR_DEVICE = -3,           /* a HIP call failed; message has the HIP error */
+    PT_ERR_IO = -4,               /* scene file could not be read or written */
+    PT_ERR_LIMIT = -5             /* a stated limit was exceeded (e.g. BVH depth > 128) */
+} pt_status;
+
+/* ---------------------------------------------------------------- scene -- */
+
+/* Pose = translation, rotation quaternion (x,y,z,w), scaling.  Same fields
+ * and meaning as class Transformation (reference src/15/transformation.hpp:6-18):
+ * apply(v) = translation + rotation * (v * scaling). */
+typedef struct pt_transform {
+    float translation[3];
+    float rotation[4];
+    float scaling[3];
+} pt_transform;
+
+/* Closed set of Animation::at(t) behaviours (reference src/15/animation.hpp:5-12,
+ * animation_constant.hpp:5-18; two-key form = AnimationSphere::at in
+ * reference src/07/pathtracer-frames.cpp:83-87). */
+enum {
+    PT_ANIM_IDENTITY = 0, /* base class: at(t) = Transformation() */
+    PT_ANIM_CONSTANT = 1, /* at(t) = T0 */
+    PT_ANIM_TWOKEY = 2    /* at(t) = mix(T0, T1, t / duration), not clamped */
+};
+typedef struct pt_animation {
+    int32_t type;
+    float duration;
+    pt_transform T0;
+    pt_transform T1;
+} pt_animation;
+
+/* Texture::value(tc, t) family (reference src/15/texture_*.hpp). */
+enum {
+    PT_TEX_CONSTANT = 0,       /* v[0..2] = value */
+    PT_TEX_IMAGE = 1,          /* width x height RGB float texels at data_offset, row 0 = bottom */
+    PT_TEX_CHECKER = 2,        /* tex0 / tex1 children, width = n, height = m */
+    PT_TEX_TRANSFORMER = 3,    /* tex0 child, v[0..1] = factor, v[2..3] = offset */
+    PT_TEX_VALUE_NOISE = 4,    /* width x height scalar lattice at data_offset */
+    PT_TEX_GRADIENT_NOISE = 5, /* width x height vec2 lattice at data_offset */
+    PT_TEX_WORLEY_NOISE = 6    /* width = number of vec2 feature points at data_offset */
+};
+typedef struct pt_texture {
+    int32_t type;
+    int32_t width, height;
+    int32_t tex0, tex1;
+    int32_t reserved;
+    uint64_t data_offset; /* in floats, into pt_scene_desc.texels */
+    float v[4];
+} pt_texture;
+
+/* Material::{Le, scatter, scatterToDirection} family (reference src/15/material*.hpp). */
+enum {
+    PT_MAT_BASE = 0,       /* base class: black, ScatterNone */
+    PT_MAT_LIGHT = 1,      /* v[0..2] = radiance */
+    PT_MAT_LAMBERTIAN = 2, /* tex[0] = albedo */
+    PT_MAT_PHONG = 3,      /* tex[0..4] = k_d, k_s, s, opacity (-1 = none), normal (-1 = none) */
+    PT_MAT_MIRROR = 4,     /* tex[0] = color */
+    PT_MAT_GLASS = 5,      /* v[0..2] = absorption, v[3] = refractive index */
+    PT_MAT_TWOSIDED = 6    /* front / back = material indices */
+};
+typedef struct pt_material {
+    int32_t type;
+    int32_t tex[5];
+    int32_t front, back;
+    float v[4];
+} pt_material;
+
+/* One Mesh (reference src/15/mesh.hpp:61-102).  Vertices of all meshes are
+ * concatenated in the four vertex streams of the scene; indices are relative
+ * to first_vertex, three per triangle, starting at indices[first_index]. */
+typedef struct pt_mesh {
+    uint32_t first_vertex, n_vertices;
+    uint32_t first_index, n_triangles;
+    int32_t has_normals, has_texcoords, has_tangents;
+    int32_t material;
+    int32_t animation; /* -1 = none */
+    int32_t reserved;
+} pt_mesh;
+
+/* One SurfaceSphere (reference src/15/surface_sphere.hpp:40-48). */
+typedef struct pt_sphere {
+    float center[3];
+    float radius;
+    int32_t material;
+    int32_t animation; /* -1 = none */
+} pt_sphere;
+
+/* Entry i describes Scene::surfaces[i] (reference src/15/scene.hpp:19); the
+ * index i is the surface id reported in pt_hit and used in pt_bvh_node. */
+enum { PT_SURF_TRIANGLE = 0, PT_SURF_SPHERE = 1 };
+typedef struct pt_surface {
+    uint32_t type;
+    uint32_t owner; /* mesh index or sphere index */
+    uint32_t index; /* triangle number inside the mesh; 0 for spheres */
+    uint32_t reserved;
+} pt_surface;
+
+/* One BVHNodeLinear (reference src/15/bvh.hpp:125-133), with the surface
+ * pointer of a leaf replaced by 2 * surface id.  link even: leaf, surface =
+ * link / 2.  link odd: inner node, first child = this index + 1, second
+ * child = link / 2.  Nodes are in the reference's pre-order. */
+typedef struct pt_bvh_node {
+    float lo[3];
+    float hi[3];
+    uint64_t link;
+} pt_bvh_node;
+
+/* Scene::envMap (reference src/15/envmap*.hpp). */
+enum {
+    PT_ENV_NONE = 0,     /* envMap is null: a miss adds nothing */
+    PT_ENV_BASE = 1,     /* base class: value = 0 */
+    PT_ENV_EQUIRECT = 2, /* tex[0] = map */
+    PT_ENV_CUBE = 3      /* tex[0..5] = +x, -x, +y, -y, +z, -z */
+};
+typedef struct pt_envmap {
+    int32_t type;
+    int32_t tex[6];
+    int32_t reserved;
+} pt_envmap;
+
+/* Flat image of a reference Scene after buildBVH (reference src/15/scene.hpp:13-73). */
+typedef struct pt_scene_desc {
+    uint32_t abi_version; /* PT_ABI_VERSION */
+    uint32_t reserved;
+    uint64_t n_vertices;
+    const float* positions; /* 3 per vertex */
+    const float* normals;   /* 3 per vertex; read only where pt_mesh.has_normals */
+    const float* texcoords; /* 2 per vertex; read only where pt_mesh.has_texcoords */
+    const float* tangents;  /* 3 per vertex; read only where pt_mesh.has_tangents */
+    uint64_t n_indices;
+    const uint32_t* indices;
+    uint64_t n_meshes;
+    const pt_mesh* meshes;
+    uint64_t n_spheres;
+    const pt_sphere* spheres;
+    uint64_t n_surfaces;
+    const pt_surface* surfaces;
+    uint64_t n_lights;
+    const uint32_t* lights; /* surface ids, in Scene::lights order */
+    uint64_t n_materials;
+    const pt_material* materials;
+    uint64_t n_textures;
+    const pt_texture* textures;
+    uint64_t n_texels;
+    const float* texels;
+    uint64_t n_animations;
+    const pt_animation* animations;
+    uint64_t n_bvh_nodes; /* 2 * n_surfaces - 1, or 0 if not built yet */
+    const pt_bvh_node* bvh_nodes;
+    pt_envmap envmap;
+} pt_scene_desc;
+
+/* Camera (reference src/15/camera.hpp:11-32): frustum corners at distance 1,
+ * thin-lens parameters and an optional pose animation. */
+typedef struct pt_camera {
+    float t, b, r, l;
+    float focus_distance;
+    float aperture_radius;
+    int32_t has_animation;
+    pt_animation animation;
+} pt_camera;
+
+/* ---------------------------------------------------------------- render -- */
+
+#define PT_RENDER_SUM_ONLY 1u /* write the plain sum over the sample range, do not divide by spp */
+
+/* Parameters of one render call.  width, height, sqrt_spp, t0, t1 are the
+ * literals of the reference loop (src/15/pathtracer.cpp:136-139,215); the
+ * rest are knobs the reference lacks.  Zero-initialised optional fields give
+ * the reference behaviour: whole image, all sqrt_spp^2 samples, at most 128
+ * path segments, Russian roulette from segment 5. */
+typedef struct pt_render_params {
+    int32_t width, height, sqrt_spp;
+    float t0, t1;
+    uint32_t flags;
+    uint64_t seed;
+    int32_t tile_x0, tile_y0, tile_x1, tile_y1; /* pixel rectangle [x0,x1) x [y0,y1); all 0 = whole image */
+    int32_t sample_begin, sample_end;           /* sample indices [begin,end) of sqrt_spp^2; both 0 = all */
+    int32_t max_path_segments;                  /* 0 = 128 */
+    int32_t rr_start_segment;                   /* 0 = 5; use -1 for "from the first segment" */
+} pt_render_params;
+
+/* Closest hit of one ray: what HitRecord (reference src/15/surface.hpp:9-30)
+ * carries that identifies the hit. surface = 0xFFFFFFFF on a miss. */
+#define PT_NO_HIT 0xFFFFFFFFu
+typedef struct pt_hit {
+    uint32_t surface;
+    uint32_t material;
+    float a;
+    uint32_t backside;
+} pt_hit;
+
+/* Work counters of the reference algorithm, summed over a render call
+ * (definitions: one ray = one BVHTreeLinear::hit call). */
+typedef struct pt_counters {
+    uint64_t path_samples;
+    uint64_t rays;         /* BVH closest-hit queries (path segments + shadow rays) */
+    uint64_t node_visits;  /* AABB slab tests */
+    uint64_t leaf_tests;   /* primitive tests reached through leaves */
+    uint64_t light_tests;  /* primitive tests made by light pdf evaluation */
+    uint64_t vertices;     /* path vertices shaded (hits) */
+    uint64_t rng_draws;
+} pt_counters;
+
+typedef struct pt_scene pt_scene; /* opaque: a scene resident in HBM on one GPU */
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char* pt_last_error(void);
+
+/* Library version string; also usable as a load check. */
+const char* pt_version(void);
+
+/* Number of visible GPUs (0 without a GPU; never fails). */
+int pt_device_count(void);
+
+/* Upload a flat scene to GPU `device`.  Replaces the implicit "scene is in
+ * host memory" state at reference src/15/pathtracer.cpp:198.  The desc must
+ * include the BVH (n_bvh_nodes == 2 * n_surfaces - 1).  The host arrays may
+ * be freed after the call. */
+int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out_scene);
+
+/* Replace the acceleration structure (per-frame rebuild over a new shutter
+ * interval: reference src/07/pathtracer-frames.cpp:209-211). */
+int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_nodes);
+
+void pt_scene_destroy(pt_scene* scene);
+
+/* Render into a host buffer of 3 * width * height floats: pixel (x, y) at
+ * out_rgb[3 * (y * width + x)], y = 0 is the bottom row, linear radiance,
+ * mean over the samples -- the contents of `img` after the loop at reference
+ * src/15/pathtracer.cpp:199-221.  Pixels outside the tile are left untouched. */
+int pt_render(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+              float* out_rgb);
+
+/* Same, into device memory on the scene's GPU, enqueued on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = default stream).  Asynchronous. */
+int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+                     float* d_out_rgb, void* hip_stream);
+
+/* Closest hits of n caller-supplied rays: BVHTreeLinear::hit(ray, amin, amax)
+ * (reference src/15/bvh.hpp:183-213) for each.  Host arrays: origins and
+ * directions 3 floats per ray, times 1 per ray (may be NULL = 0). */
+int pt_trace_rays(pt_scene* scene, uint64_t n_rays, const float* origins, const float* directions,
+                  const float* times, float amin, float amax, pt_hit* out_hits);
+
+/* Closest hit of the camera ray of every (pixel, sample) of a render call,
+ * in pixel-major, sample-minor order: n = tile pixels * samples entries. */
+int pt_primary_hits(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+                    pt_hit* out_hits);
+
+/* Radiance of every single path sample of a render call (same order as
+ * pt_primary_hits), 3 floats each: the return values of pathSample
+ * (reference src/15/pathtracer.cpp:50-130) before accumulation. */
+int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+                      float* out_rgb_per_sample);
+
+/* Render with instrumentation: fills the work counters of the reference
+ * algorithm for this call (slower than pt_render; same image). */
+int pt_render_counted(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+                      float* out_rgb, pt_counters* out_counters);
+
+/* Milliseconds the GPU spent in the kernels of the last pt_render* call on
+ * this scene (HIP events on the launch stream); negative if none yet. */
+float pt_last_kernel_ms(pt_scene* scene);
+
+/* ------------------------------------------------------- host-side helpers -- */
+
+/* Build the acceleration structure over [t0, t1] exactly as
+ * BVHNode::buildBVH + BVHTreeLinear::flattenBVH do (reference
+ * src/15/bvh.hpp:36-108,146-176): same surface bounds, same per-node sort
+ * along the longest axis, same SAH sweep, same pre-order.  out_nodes must
+ * hold 2 * n_surfaces - 1 entries.  Fails with PT_ERR_LIMIT if the tree is
+ * deeper than 128 levels (the reference aborts there). */
+int pt_bvh_build(const pt_scene_desc* desc, float t0, float t1, pt_bvh_node* out_nodes,
+                 uint32_t* out_depth);
+
+/* Per-vertex tangents of one mesh as Mesh's constructor computes them
+ * (reference src/15/mesh.hpp:10-55). */
+int pt_mesh_compute_tangents(const float* positions, const float* normals, const float* texcoords,
+                             uint32_t n_vertices, const uint32_t* indices, uint32_t n_triangles,
+                             float* out_tangents);
+
+/* Scene files (".ptscene"): a flat scene serialised verbatim.  The loaded
+ * desc owns its arrays; release it with pt_scene_desc_free. */
+int pt_scene_desc_load(const char* path, pt_scene_desc** out_desc);
+int pt_scene_desc_save(const pt_scene_desc* desc, const char* path);
+void pt_scene_desc_free(pt_scene_desc* desc);
+
+/* Check indices and sizes of a desc (every index in range, node count,
+ * acyclic texture / material references).  Called by pt_scene_create. */
+int pt_scene_desc_validate(const pt_scene_desc* desc);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PT_AMD_H */
