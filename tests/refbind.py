@@ -228,3 +228,111 @@ def make_params(width, height, sqrt_spp, seed=42, t0=0.0, t1=0.0, tile=None, sam
     p.max_path_segments = max_path_segments
     p.rr_start_segment = rr_start_segment
     return p
+
+
+class Oracle:
+    """The CPU restatement (oracle/libpt_oracle.so). math_mode 0 = C library, 1 = portable."""
+
+    def __init__(self, path=ORACLE_LIB):
+        self.lib = C.CDLL(path)
+        self.lib.oracle_last_error.restype = C.c_char_p
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RefError(self.lib.oracle_last_error().decode())
+
+    def render(self, desc, cam, params, math_mode=1, threads=0, counters=False):
+        out = np.zeros((params.height, params.width, 3), np.float32)
+        cnt = abi.pt_counters()
+        self._check(self.lib.oracle_render(desc, C.byref(cam), C.byref(params), math_mode, threads, _f(out),
+                                           C.byref(cnt)))
+        return (out, cnt) if counters else out
+
+    def render_samples(self, desc, cam, params, math_mode=1):
+        out = np.empty((_n_samples(params), 3), np.float32)
+        self._check(self.lib.oracle_render_samples(desc, C.byref(cam), C.byref(params), math_mode, _f(out)))
+        return out
+
+    def primary_hits(self, desc, cam, params, math_mode=1):
+        out = (abi.pt_hit * _n_samples(params))()
+        self._check(self.lib.oracle_primary_hits(desc, C.byref(cam), C.byref(params), math_mode, out))
+        return hits_to_numpy(out)
+
+    def camera_rays(self, desc, cam, params, math_mode=1):
+        out = np.empty((_n_samples(params), 7), np.float32)
+        self._check(self.lib.oracle_camera_rays(desc, C.byref(cam), C.byref(params), math_mode, _f(out)))
+        return out
+
+    def trace_rays(self, desc, origins, directions, times=None, amin=1e-4, amax=np.finfo(np.float32).max,
+                   math_mode=1):
+        origins = np.ascontiguousarray(origins, np.float32)
+        directions = np.ascontiguousarray(directions, np.float32)
+        n = len(origins)
+        tp = None
+        if times is not None:
+            times = np.ascontiguousarray(times, np.float32)
+            tp = _f(times)
+        out = (abi.pt_hit * n)()
+        self._check(self.lib.oracle_trace_rays(desc, C.c_uint64(n), _f(origins), _f(directions), tp,
+                                               C.c_float(amin), C.c_float(amax), math_mode, out))
+        return hits_to_numpy(out)
+
+    def kat_warp(self, which, u0, u1, param=None, math_mode=0):
+        u0 = np.ascontiguousarray(u0, np.float32)
+        u1 = np.ascontiguousarray(u1, np.float32)
+        param = np.ascontiguousarray(param if param is not None else np.zeros_like(u0), np.float32)
+        out = np.empty((u0.size, 3), np.float32)
+        self._check(self.lib.oracle_kat_warp(which, C.c_uint64(u0.size), _f(u0), _f(u1), _f(param), math_mode,
+                                             _f(out)))
+        return out
+
+    def kat_tangentspace(self, normals, vecs):
+        normals = np.ascontiguousarray(normals, np.float32)
+        vecs = np.ascontiguousarray(vecs, np.float32)
+        out = np.empty_like(vecs)
+        self._check(self.lib.oracle_kat_tangentspace(C.c_uint64(len(vecs)), _f(normals), _f(vecs), _f(out)))
+        return out
+
+    def kat_fresnel(self, cosI, cosT, n1, n2):
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (cosI, cosT, n1, n2)]
+        out = np.empty_like(arrs[0])
+        self._check(self.lib.oracle_kat_fresnel(C.c_uint64(out.size), *[_f(a) for a in arrs], _f(out)))
+        return out
+
+    def kat_refract(self, i3, n3, eta):
+        i3 = np.ascontiguousarray(i3, np.float32)
+        n3 = np.ascontiguousarray(n3, np.float32)
+        eta = np.ascontiguousarray(eta, np.float32)
+        out = np.empty_like(i3)
+        self._check(self.lib.oracle_kat_refract(C.c_uint64(len(eta)), _f(i3), _f(n3), _f(eta), _f(out)))
+        return out
+
+    def kat_texture(self, desc, tex_id, tc):
+        tc = np.ascontiguousarray(tc, np.float32)
+        out = np.empty((len(tc), 3), np.float32)
+        self._check(self.lib.oracle_kat_texture(desc, tex_id, C.c_uint64(len(tc)), _f(tc), _f(out)))
+        return out
+
+    def kat_envmap(self, desc, dirs, math_mode=0):
+        dirs = np.ascontiguousarray(dirs, np.float32)
+        out = np.empty((len(dirs), 3), np.float32)
+        self._check(self.lib.oracle_kat_envmap(desc, C.c_uint64(len(dirs)), _f(dirs), math_mode, _f(out)))
+        return out
+
+    def kat_animation(self, anim, t, math_mode=0):
+        T = abi.pt_transform()
+        self._check(self.lib.oracle_kat_animation(C.byref(anim), C.c_float(t), math_mode, C.byref(T)))
+        return T
+
+    def kat_math(self, fn, x, y=None, math_mode=1):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+        out = np.empty_like(x)
+        self._check(self.lib.oracle_kat_math(fn, C.c_uint64(x.size), _f(x), _f(y), math_mode, _f(out)))
+        return out
+
+    def kat_rng(self, seed, pixel, sample, n):
+        out = np.empty(n, np.float32)
+        self._check(self.lib.oracle_kat_rng(C.c_uint64(seed), C.c_uint64(pixel), C.c_uint64(sample), C.c_uint32(n),
+                                            _f(out)))
+        return out
