@@ -1,0 +1,661 @@
+// pt_kernels.hip -- kernels and the device half of the C ABI (include/pt_amd.h).
+//
+// Kernels (gfx950, wave64):
+//   renderPixelsKernel   one lane per pixel; the lane walks its pixel's
+//                        samples in order and adds them in order, so the sum
+//                        is the same float sequence as the reference's loop
+//                        (reference src/15/pathtracer.cpp:207-220).  A wave
+//                        covers an 8x8 pixel tile.
+//   renderSamplesKernel  one lane per (pixel, sample): per-sample radiance
+//   primaryHitsKernel    one lane per (pixel, sample): closest hit of the camera ray
+//   traceRaysKernel      one lane per caller-supplied ray
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pt_amd.h"
+#include "pt_device.hpp"
+#include "pt_internal.hpp"
+
+using namespace ptd;
+using ptint::fail;
+
+namespace {
+
+struct RenderArgs {
+    pt_camera cam;
+    pt_render_params p;
+    int x0, y0, tw, th; // tile origin and size
+    int s0, s1;         // sample range
+    PathParams pp;
+};
+
+// pixel of the tile handled by this lane: 8x8 pixels per wave, 16x16 per 256-thread block
+PT_DEV bool lanePixel(const RenderArgs& a, int& x, int& y)
+{
+    const int tilesX = (a.tw + 15) / 16;
+    const int bx = blockIdx.x % tilesX;
+    const int by = blockIdx.x / tilesX;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int lx = ((wave & 1) << 3) + (lane & 7);
+    const int ly = ((wave >> 1) << 3) + (lane >> 3);
+    x = bx * 16 + lx;
+    y = by * 16 + ly;
+    bool ok = x < a.tw && y < a.th;
+    x += a.x0;
+    y += a.y0;
+    return ok;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) renderPixelsKernel(DevScene sc, RenderArgs a, float* __restrict__ out,
+                                                          unsigned long long* __restrict__ counters)
+{
+    int x, y;
+    if (!lanePixel(a, x, y))
+        return;
+    const uint64_t pixel = uint64_t(y) * a.p.width + x;
+    Counters cnt = { 0, 0, 0, 0, 0, 0 };
+    V3 acc = v3(0.0f);
+    for (int smp = a.s0; smp < a.s1; smp++) {
+        Rng<COUNT> rng;
+        rng.key = pt_rng_key(a.p.seed, pixel, uint64_t(smp));
+        rng.n = 0;
+        rng.cnt = &cnt;
+        Ray ray = sampleRay<COUNT>(a.cam, a.p, x, y, smp, rng);
+        acc = acc + pathSample<COUNT>(sc, a.pp, ray, rng, &cnt);
+    }
+    if (!(a.p.flags & PT_RENDER_SUM_ONLY))
+        acc = acc / float(a.p.sqrt_spp * a.p.sqrt_spp);
+    out[3 * pixel + 0] = acc.x;
+    out[3 * pixel + 1] = acc.y;
+    out[3 * pixel + 2] = acc.z;
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)cnt.rays);
+        atomicAdd(&counters[1], (unsigned long long)cnt.nodeVisits);
+        atomicAdd(&counters[2], (unsigned long long)cnt.leafTests);
+        atomicAdd(&counters[3], (unsigned long long)cnt.lightTests);
+        atomicAdd(&counters[4], (unsigned long long)cnt.vertices);
+        atomicAdd(&counters[5], (unsigned long long)cnt.draws);
+    }
+}
+
+// index k -> (pixel of the tile in row-major order, sample)
+PT_DEV void sampleOfIndex(const RenderArgs& a, uint64_t k, int& x, int& y, int& smp)
+{
+    const int ns = a.s1 - a.s0;
+    uint64_t tp = k / ns;
+    smp = a.s0 + int(k % ns);
+    x = a.x0 + int(tp % a.tw);
+    y = a.y0 + int(tp / a.tw);
+}
+
+__global__ void __launch_bounds__(256) renderSamplesKernel(DevScene sc, RenderArgs a, uint64_t n, float* __restrict__ out)
+{
+    uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    int x, y, smp;
+    sampleOfIndex(a, k, x, y, smp);
+    Rng<false> rng;
+    rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
+    rng.n = 0;
+    rng.cnt = nullptr;
+    Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+    V3 v = pathSample<false>(sc, a.pp, ray, rng, nullptr);
+    out[3 * k + 0] = v.x;
+    out[3 * k + 1] = v.y;
+    out[3 * k + 2] = v.z;
+}
+
+PT_DEV pt_hit toHit(const DevScene& sc, const Ray& ray, const HitLite& h)
+{
+    pt_hit r;
+    if (h.sid == PT_NO_HIT) {
+        r.surface = PT_NO_HIT;
+        r.material = PT_NO_HIT;
+        r.a = 0.0f;
+        r.backside = 0;
+    } else {
+        Hit hr = makeHit(sc, ray, h);
+        r.surface = h.sid;
+        r.material = uint32_t(hr.material);
+        r.a = h.a;
+        r.backside = hr.backside ? 1u : 0u;
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) primaryHitsKernel(DevScene sc, RenderArgs a, uint64_t n, pt_hit* __restrict__ out)
+{
+    uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    int x, y, smp;
+    sampleOfIndex(a, k, x, y, smp);
+    Rng<false> rng;
+    rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
+    rng.n = 0;
+    rng.cnt = nullptr;
+    Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+    HitLite h = closestHit<false>(sc, ray, 0.0001f, kFltMax, nullptr);
+    out[k] = toHit(sc, ray, h);
+}
+
+__global__ void __launch_bounds__(256) traceRaysKernel(DevScene sc, uint64_t n, const float* __restrict__ origins,
+                                                       const float* __restrict__ dirs, const float* __restrict__ times,
+                                                       float amin, float amax, pt_hit* __restrict__ out)
+{
+    uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= n)
+        return;
+    Ray ray = makeRay(v3(origins + 3 * k), v3(dirs + 3 * k), times ? times[k] : 0.0f);
+    HitLite h = closestHit<false>(sc, ray, amin, amax, nullptr);
+    out[k] = toHit(sc, ray, h);
+}
+
+// ------------------------------------------------------------------- host --
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+int upload(const T* host, size_t count, T** dev, std::vector<void*>& owned)
+{
+    *dev = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    owned.push_back(p);
+    if (count > 0)
+        HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T*>(p);
+    return PT_OK;
+}
+
+} // namespace
+
+struct pt_scene {
+    int device = 0;
+    DevScene dev;
+    std::vector<void*> owned; // every device allocation of the scene
+    float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
+    uint64_t n_surfaces = 0;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+// Convert the reference-order node array into device nodes with escape links.
+int buildDeviceNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& out)
+{
+    out.resize(2 * n);
+    std::vector<uint32_t> escape(n);
+    // pre-order walk with an explicit stack of (node, escape)
+    std::vector<std::pair<uint32_t, uint32_t>> stack;
+    stack.push_back({ 0u, uint32_t(n) });
+    uint64_t visited = 0;
+    while (!stack.empty()) {
+        auto [k, esc] = stack.back();
+        stack.pop_back();
+        if (++visited > n)
+            return fail(PT_ERR_INVALID_ARGUMENT, "acceleration structure is not a tree");
+        escape[k] = esc;
+        uint64_t link = nodes[k].link;
+        if (link % 2 == 1) {
+            uint32_t c2 = uint32_t(link / 2);
+            stack.push_back({ c2, esc });
+            stack.push_back({ k + 1, c2 });
+        }
+    }
+    if (visited != n)
+        return fail(PT_ERR_INVALID_ARGUMENT, "acceleration structure has unreachable nodes");
+    for (uint64_t k = 0; k < n; k++) {
+        const pt_bvh_node& nd = nodes[k];
+        uint32_t leaf = (nd.link % 2 == 0) ? uint32_t(nd.link / 2) : kInner;
+        out[2 * k + 0] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
+        out[2 * k + 1] = make_float4(nd.hi[1], nd.hi[2], __builtin_bit_cast(float, escape[k]), __builtin_bit_cast(float, leaf));
+    }
+    return PT_OK;
+}
+
+int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_params* p, const void* out, RenderArgs& a)
+{
+    if (!scene || !camera || !p || !out)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->width <= 0 || p->height <= 0 || p->sqrt_spp <= 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "width, height and sqrt_spp must be positive");
+    if (p->sqrt_spp > 46340 || uint64_t(p->width) * uint64_t(p->height) > 0x7FFFFFFFull)
+        return fail(PT_ERR_LIMIT, "image or sample count too large");
+    int x0 = p->tile_x0, y0 = p->tile_y0, x1 = p->tile_x1, y1 = p->tile_y1;
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) {
+        x1 = p->width;
+        y1 = p->height;
+    }
+    int s0 = p->sample_begin, s1 = p->sample_end;
+    if (s0 == 0 && s1 == 0)
+        s1 = p->sqrt_spp * p->sqrt_spp;
+    if (x0 < 0 || y0 < 0 || x1 > p->width || y1 > p->height || x0 > x1 || y0 > y1)
+        return fail(PT_ERR_INVALID_ARGUMENT, "tile rectangle outside the image");
+    if (s0 < 0 || s1 > p->sqrt_spp * p->sqrt_spp || s0 > s1)
+        return fail(PT_ERR_INVALID_ARGUMENT, "sample range outside [0, sqrt_spp^2]");
+    if (camera->has_animation
+        && (camera->animation.type < PT_ANIM_IDENTITY || camera->animation.type > PT_ANIM_TWOKEY))
+        return fail(PT_ERR_UNSUPPORTED, "camera animation has an unknown type");
+    a.cam = *camera;
+    a.p = *p;
+    a.x0 = x0;
+    a.y0 = y0;
+    a.tw = x1 - x0;
+    a.th = y1 - y0;
+    a.s0 = s0;
+    a.s1 = s1;
+    a.pp.maxSegments = p->max_path_segments > 0 ? p->max_path_segments : 128;
+    a.pp.rrStart = p->rr_start_segment == 0 ? 5 : (p->rr_start_segment < 0 ? 0 : p->rr_start_segment);
+    return PT_OK;
+}
+
+int launchRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream, unsigned long long* d_counters)
+{
+    if (a.tw == 0 || a.th == 0)
+        return PT_OK;
+    const int tilesX = (a.tw + 15) / 16, tilesY = (a.th + 15) / 16;
+    dim3 grid(unsigned(tilesX) * unsigned(tilesY)), block(256);
+    HIP_TRY(hipEventRecord(scene->evStart, stream));
+    if (d_counters)
+        hipLaunchKernelGGL(renderPixelsKernel<true>, grid, block, 0, stream, scene->dev, a, d_out, d_counters);
+    else
+        hipLaunchKernelGGL(renderPixelsKernel<false>, grid, block, 0, stream, scene->dev, a, d_out, d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(scene->evStop, stream));
+    scene->timed = true;
+    return PT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+void pt_scene_destroy(pt_scene* scene)
+{
+    if (!scene)
+        return;
+    DeviceGuard g(scene->device);
+    for (void* p : scene->owned)
+        (void)hipFree(p);
+    if (scene->evStart)
+        (void)hipEventDestroy(scene->evStart);
+    if (scene->evStop)
+        (void)hipEventDestroy(scene->evStop);
+    delete scene;
+}
+
+int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
+{
+    if (!d || !out_scene)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *out_scene = nullptr;
+    int rc = pt_scene_desc_validate(d);
+    if (rc != PT_OK)
+        return rc;
+    if (d->n_surfaces == 0 || d->n_bvh_nodes != 2 * d->n_surfaces - 1)
+        return fail(PT_ERR_INVALID_ARGUMENT, "scene needs at least one surface and a built acceleration structure");
+    if (device < 0 || device >= pt_device_count())
+        return fail(PT_ERR_DEVICE, "no such GPU: " + std::to_string(device));
+    DeviceGuard g(device);
+    if (!g.ok)
+        return fail(PT_ERR_DEVICE, "cannot select GPU " + std::to_string(device));
+
+    // host-side preparation: device nodes, per-surface rows, mesh table
+    std::vector<float4> nodes;
+    rc = buildDeviceNodes(d->bvh_nodes, d->n_bvh_nodes, nodes);
+    if (rc != PT_OK)
+        return rc;
+
+    std::vector<DevMesh> meshes(d->n_meshes);
+    for (uint64_t i = 0; i < d->n_meshes; i++) {
+        const pt_mesh& m = d->meshes[i];
+        DevMesh& dm = meshes[i];
+        std::memset(&dm, 0, sizeof(dm));
+        dm.first_vertex = m.first_vertex;
+        dm.first_index = m.first_index;
+        dm.material = m.material;
+        dm.animation = m.animation;
+        dm.flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u);
+    }
+
+    auto bitsf = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    std::vector<float4> surf(3 * d->n_surfaces);
+    for (uint64_t i = 0; i < d->n_surfaces; i++) {
+        const pt_surface& s = d->surfaces[i];
+        if (s.type == PT_SURF_TRIANGLE) {
+            const pt_mesh& m = d->meshes[s.owner];
+            const uint32_t* idx = d->indices + m.first_index + 3 * size_t(s.index);
+            V3 A = v3(d->positions + 3 * size_t(m.first_vertex + idx[0]));
+            V3 B = v3(d->positions + 3 * size_t(m.first_vertex + idx[1]));
+            V3 C = v3(d->positions + 3 * size_t(m.first_vertex + idx[2]));
+            uint32_t kind = kTriStatic;
+            if (m.animation >= 0) {
+                const pt_animation& an = d->animations[m.animation];
+                if (an.type == PT_ANIM_TWOKEY) {
+                    kind = kTriDynamic;
+                } else {
+                    // a time-independent pose: apply it once, with the arithmetic of
+                    // Transformation::operator* (reference src/15/transformation.hpp:34-37)
+                    Xform T = an.type == PT_ANIM_CONSTANT ? xformOf(an.T0) : xformIdentity();
+                    A = apply(T, A);
+                    B = apply(T, B);
+                    C = apply(T, C);
+                }
+            }
+            surf[3 * i + 0] = make_float4(A.x, A.y, A.z, bitsf(kind));
+            surf[3 * i + 1] = make_float4(B.x, B.y, B.z, bitsf(s.owner));
+            surf[3 * i + 2] = make_float4(C.x, C.y, C.z, bitsf(s.index));
+        } else {
+            const pt_sphere& q = d->spheres[s.owner];
+            V3 c = v3(q.center);
+            float r = q.radius;
+            uint32_t kind = kSphStatic;
+            if (q.animation >= 0) {
+                const pt_animation& an = d->animations[q.animation];
+                if (an.type == PT_ANIM_TWOKEY) {
+                    kind = kSphDynamic;
+                } else {
+                    Xform T = an.type == PT_ANIM_CONSTANT ? xformOf(an.T0) : xformIdentity();
+                    c = apply(T, c);
+                    r *= T.scaling.x;
+                }
+            }
+            surf[3 * i + 0] = make_float4(c.x, c.y, c.z, bitsf(kind));
+            surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, 0.0f);
+            surf[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+
+    pt_scene* sc = new pt_scene;
+    sc->device = device;
+    sc->n_surfaces = d->n_surfaces;
+    std::memset(&sc->dev, 0, sizeof(sc->dev));
+    DevScene& dev = sc->dev;
+    auto bail = [&](int code) {
+        pt_scene_destroy(sc);
+        return code;
+    };
+    float4* dNodes = nullptr;
+    float4* dSurf = nullptr;
+    float *dPos = nullptr, *dNrm = nullptr, *dTc = nullptr, *dTng = nullptr, *dTexels = nullptr;
+    uint32_t *dIdx = nullptr, *dLights = nullptr;
+    DevMesh* dMeshes = nullptr;
+    pt_sphere* dSpheres = nullptr;
+    pt_material* dMats = nullptr;
+    pt_texture* dTex = nullptr;
+    pt_animation* dAnims = nullptr;
+    if ((rc = upload(nodes.data(), nodes.size(), &dNodes, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(surf.data(), surf.size(), &dSurf, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->positions, 3 * d->n_vertices, &dPos, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->normals, 3 * d->n_vertices, &dNrm, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->texcoords, 2 * d->n_vertices, &dTc, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->tangents, 3 * d->n_vertices, &dTng, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->indices, d->n_indices, &dIdx, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(meshes.data(), meshes.size(), &dMeshes, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->spheres, d->n_spheres, &dSpheres, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->lights, d->n_lights, &dLights, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->materials, d->n_materials, &dMats, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->textures, d->n_textures, &dTex, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->texels, d->n_texels, &dTexels, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(d->animations, d->n_animations, &dAnims, sc->owned)) != PT_OK) return bail(rc);
+    sc->nodes = dNodes;
+    dev.nodes = dNodes;
+    dev.surf = dSurf;
+    dev.positions = dPos;
+    dev.normals = dNrm;
+    dev.texcoords = dTc;
+    dev.tangents = dTng;
+    dev.indices = dIdx;
+    dev.meshes = dMeshes;
+    dev.spheres = dSpheres;
+    dev.lights = dLights;
+    dev.materials = dMats;
+    dev.textures = dTex;
+    dev.texels = dTexels;
+    dev.animations = dAnims;
+    dev.n_nodes = uint32_t(d->n_bvh_nodes);
+    dev.n_surfaces = uint32_t(d->n_surfaces);
+    dev.n_lights = uint32_t(d->n_lights);
+    dev.envmap = d->envmap;
+    if (hipEventCreate(&sc->evStart) != hipSuccess || hipEventCreate(&sc->evStop) != hipSuccess) {
+        pt_scene_destroy(sc);
+        return fail(PT_ERR_DEVICE, "cannot create timing events");
+    }
+    *out_scene = sc;
+    return PT_OK;
+}
+
+int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_nodes)
+{
+    if (!scene || !nodes)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_nodes != 2 * scene->n_surfaces - 1)
+        return fail(PT_ERR_INVALID_ARGUMENT, "node count is not 2 * surfaces - 1");
+    for (uint64_t i = 0; i < n_nodes; i++) {
+        uint64_t link = nodes[i].link;
+        if (link % 2 == 0 ? link / 2 >= scene->n_surfaces : (link / 2 <= i + 1 || link / 2 >= n_nodes))
+            return fail(PT_ERR_INVALID_ARGUMENT, "node " + std::to_string(i) + " has a bad link");
+    }
+    std::vector<float4> dn;
+    int rc = buildDeviceNodes(nodes, n_nodes, dn);
+    if (rc != PT_OK)
+        return rc;
+    DeviceGuard g(scene->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(scene->nodes, dn.data(), dn.size() * sizeof(float4), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* d_out_rgb,
+                     void* hip_stream)
+{
+    RenderArgs a;
+    int rc = checkRender(scene, camera, params, d_out_rgb, a);
+    if (rc != PT_OK)
+        return rc;
+    DeviceGuard g(scene->device);
+    return launchRender(scene, a, d_out_rgb, static_cast<hipStream_t>(hip_stream), nullptr);
+}
+
+static int renderToHost(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* out_rgb,
+                        pt_counters* out_counters)
+{
+    RenderArgs a;
+    int rc = checkRender(scene, camera, params, out_rgb, a);
+    if (rc != PT_OK)
+        return rc;
+    DeviceGuard g(scene->device);
+    const size_t bytes = size_t(3) * a.p.width * a.p.height * sizeof(float);
+    float* d_out = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
+    // pixels outside the tile keep the caller's values
+    hipError_t e = hipMemcpy(d_out, out_rgb, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && out_counters) {
+        e = hipMalloc(reinterpret_cast<void**>(&d_cnt), 6 * sizeof(unsigned long long));
+        if (e == hipSuccess)
+            e = hipMemset(d_cnt, 0, 6 * sizeof(unsigned long long));
+    }
+    if (e == hipSuccess) {
+        rc = launchRender(scene, a, d_out, nullptr, d_cnt);
+        if (rc == PT_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess)
+                e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && out_counters) {
+                unsigned long long c[6];
+                e = hipMemcpy(c, d_cnt, sizeof(c), hipMemcpyDeviceToHost);
+                out_counters->path_samples = uint64_t(a.tw) * a.th * (a.s1 - a.s0);
+                out_counters->rays = c[0];
+                out_counters->node_visits = c[1];
+                out_counters->leaf_tests = c[2];
+                out_counters->light_tests = c[3];
+                out_counters->vertices = c[4];
+                out_counters->rng_draws = c[5];
+            }
+        }
+    }
+    (void)hipFree(d_out);
+    if (d_cnt)
+        (void)hipFree(d_cnt);
+    if (rc != PT_OK)
+        return rc;
+    if (e != hipSuccess)
+        return fail(PT_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_render(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* out_rgb)
+{
+    return renderToHost(scene, camera, params, out_rgb, nullptr);
+}
+
+int pt_render_counted(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* out_rgb,
+                      pt_counters* out_counters)
+{
+    if (!out_counters)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    return renderToHost(scene, camera, params, out_rgb, out_counters);
+}
+
+float pt_last_kernel_ms(pt_scene* scene)
+{
+    if (!scene || !scene->timed)
+        return -1.0f;
+    DeviceGuard g(scene->device);
+    if (hipEventSynchronize(scene->evStop) != hipSuccess)
+        return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, scene->evStart, scene->evStop) != hipSuccess)
+        return -1.0f;
+    return ms;
+}
+
+int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+                      float* out_rgb_per_sample)
+{
+    RenderArgs a;
+    int rc = checkRender(scene, camera, params, out_rgb_per_sample, a);
+    if (rc != PT_OK)
+        return rc;
+    const uint64_t n = uint64_t(a.tw) * a.th * (a.s1 - a.s0);
+    if (n == 0)
+        return PT_OK;
+    if (n > (uint64_t(1) << 31))
+        return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
+    DeviceGuard g(scene->device);
+    float* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * 3 * sizeof(float)));
+    hipLaunchKernelGGL(renderSamplesKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, a, n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpy(out_rgb_per_sample, d_out, n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess)
+        return fail(PT_ERR_DEVICE, std::string("render_samples: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_primary_hits(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, pt_hit* out_hits)
+{
+    RenderArgs a;
+    int rc = checkRender(scene, camera, params, out_hits, a);
+    if (rc != PT_OK)
+        return rc;
+    const uint64_t n = uint64_t(a.tw) * a.th * (a.s1 - a.s0);
+    if (n == 0)
+        return PT_OK;
+    if (n > (uint64_t(1) << 31))
+        return fail(PT_ERR_LIMIT, "too many samples for one call");
+    DeviceGuard g(scene->device);
+    pt_hit* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(pt_hit)));
+    hipLaunchKernelGGL(primaryHitsKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, a, n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpy(out_hits, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess)
+        return fail(PT_ERR_DEVICE, std::string("primary_hits: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_trace_rays(pt_scene* scene, uint64_t n, const float* origins, const float* directions, const float* times,
+                  float amin, float amax, pt_hit* out_hits)
+{
+    if (!scene || !origins || !directions || !out_hits)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0)
+        return PT_OK;
+    if (n > (uint64_t(1) << 31))
+        return fail(PT_ERR_LIMIT, "too many rays for one call");
+    DeviceGuard g(scene->device);
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    pt_hit* d_out = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_d), n * 3 * sizeof(float));
+    if (e == hipSuccess && times) e = hipMalloc(reinterpret_cast<void**>(&d_t), n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(pt_hit));
+    if (e == hipSuccess) e = hipMemcpy(d_o, origins, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, directions, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && times) e = hipMemcpy(d_t, times, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(traceRaysKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, n, d_o,
+                           d_d, d_t, amin, amax, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out_hits, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost);
+    if (d_o) (void)hipFree(d_o);
+    if (d_d) (void)hipFree(d_d);
+    if (d_t) (void)hipFree(d_t);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess)
+        return fail(PT_ERR_DEVICE, std::string("trace_rays: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+} // extern "C"
