@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X render loop: path samples / s at 1080p.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full render of the workload (all pixels, all samples) on every
+rank.  N = 1 renders the Cornell box with glossy (Phong) boxes and MIS at
+1920x1080, 1024 spp -- the configuration the metric is quoted on.  With N > 1
+(launched one process per GPU by torch.distributed.run) every rank renders its
+own 1024-spp batch of the same frame (rank-specific seed: weak scaling) and the
+float sum buffers are combined on rank 0 with one RCCL reduce inside the timed
+region.  Rank 0 prints one JSON line.
+
+The line also carries
+  roofline      algorithmic bytes of the reference algorithm (per-sample counts
+                measured by the instrumented kernel on the same scene) divided
+                by the kernel's duration from HIP events on the launch stream,
+                against the HBM peak; and the same for FP32 vector flops,
+  cpu_baseline  the compiled reference (oracle/_ref/libpt_ref_fast.so: the
+                reference's own pathSample / BVH / material code with its
+                shipped optimisation level) timed on this machine's host cores
+                on a reduced-spp render of the same scene.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # HBM3E peak, GB/s
+VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak, TFLOP/s
+
+
+def workload(name):
+    import path_tracing_amd as pt
+    golden = os.path.join(ROOT, "tests", "golden")
+    if name == "cornell":
+        scene = pt.LoadedScene(os.path.join(golden, "cornell_glossy.ptscene"))
+        cam = pt.load_camera(os.path.join(golden, "cornell_wide.ptcam"))
+        return scene, cam, "cornell-box glossy+MIS 1920x1080 1024spp", 32
+    if name.startswith("mesh"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenes
+        n = int(name[4:] or 1000)
+        s, cam = scenes.big_mesh_scene(n)
+        return s, cam, "displaced grid %d triangles 1920x1080 256spp" % (2 * n * n + 2), 16
+    raise SystemExit("unknown workload " + name)
+
+
+def algorithmic_per_sample(cnt, n_lights):
+    """Bytes and flops per path sample of the reference algorithm, from measured work counts:
+    32 B per node visit, 48 B per leaf primitive test, 48 B per light-pdf primitive test, 12 B of
+    output; ~30 flops per slab test, ~60 per primitive test, ~300 per shaded vertex."""
+    n = max(cnt["path_samples"], 1)
+    bytes_ = (cnt["node_visits"] * 32 + cnt["leaf_tests"] * 48 + cnt["light_tests"] * 48) / n + 12
+    flops = (cnt["node_visits"] * 30 + (cnt["leaf_tests"] + cnt["light_tests"]) * 60 + cnt["vertices"] * 300) / n
+    return bytes_, flops
+
+
+def cpu_baseline(scene, cam, width, height, seed):
+    """Time the compiled reference on the host cores on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refbind
+    import path_tracing_amd as pt
+    lib = refbind.REF_FAST_LIB if os.path.exists(refbind.REF_FAST_LIB) else refbind.REF_LIB
+    if not os.path.exists(lib):
+        return None
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    R = refbind.Reference(lib)
+    d = scene.desc()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(2)
+    os.dup2(devnull, 2)  # the reference prints progress on stderr
+    try:
+        rs = R.scene(C.byref(d))
+        # calibrate on 1 spp, then pick sqrt_spp for roughly 15 s
+        p = pt.make_params(width, height, 1, seed=seed)
+        _, t1 = rs.render(cam, p, rng_mode=1, threads=threads)
+        rate = width * height / max(t1, 1e-6)
+        sqrt_spp = max(1, min(8, int((15.0 * rate / (width * height)) ** 0.5)))
+        p = pt.make_params(width, height, sqrt_spp, seed=seed)
+        _, secs = rs.render(cam, p, rng_mode=1, threads=threads)
+    finally:
+        os.dup2(saved, 2)
+        os.close(devnull)
+        os.close(saved)
+    n = width * height * sqrt_spp * sqrt_spp
+    return {"value": n / secs, "unit": "path samples/s", "cores": threads, "kind": "reference",
+            "sample": "%dx%d at %d spp (%d path samples, %.1f s), reference's own generator, "
+                      "g++ -Ofast -march=x86-64-v3 -fopenmp" % (width, height, sqrt_spp * sqrt_spp, n, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sqrt-spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import path_tracing_amd as pt
+    from path_tracing_amd import abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus does not match WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene, cam, label, default_sqrt = workload(args.workload)
+    sqrt_spp = args.sqrt_spp or default_sqrt
+    W, H = args.width, args.height
+    spp = sqrt_spp * sqrt_spp
+    dev = pt.DeviceScene(scene, device=local_rank)
+    out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    # every rank renders its own batch of samples of the same frame (its own seed)
+    params = pt.make_params(W, H, sqrt_spp, seed=42 + rank, flags=abi.PT_RENDER_SUM_ONLY if world > 1 else 0)
+
+    events = []
+
+    def step(timed=False):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        dev.render_device(cam, params, out.data_ptr(), stream.cuda_stream)
+        if timed:
+            e1.record(stream)
+            events.append((e0, e1))
+        if world > 1:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                out.mul_(1.0 / (spp * world))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # average duration of the render kernel: HIP events on the launch stream around each launch
+    last_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / len(events)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        total_samples = float(W) * H * spp * world * args.steps
+        value = total_samples / elapsed
+        # work counts of the reference algorithm on this scene (instrumented kernel, reduced spp)
+        cparams = pt.make_params(W // 4, H // 4, min(sqrt_spp, 4), seed=42)
+        _, cnt = dev.render_counted(cam, cparams)
+        cnt = cnt.as_dict()
+        bytes_ps, flops_ps = algorithmic_per_sample(cnt, 0)
+        launch_samples = float(W) * H * spp
+        kern_s = last_ms * 1e-3
+        ach_gbs = bytes_ps * launch_samples / kern_s / 1e9
+        ach_tf = flops_ps * launch_samples / kern_s / 1e12
+        result = {
+            "metric": "path samples/sec at 1080p", "value": value, "unit": "path samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "width": W, "height": H, "spp": spp, "samples_per_step": launch_samples * world,
+                       "sharding": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "renderPixelsKernel", "kernel_ms": last_ms,
+                         "algorithmic_bytes_per_sample": bytes_ps,
+                         "note": "algorithmic bytes = 32 B/node visit + 48 B/primitive test + 12 B/sample of the "
+                                 "reference algorithm; a fraction above 1 means the working set is served from "
+                                 "cache, i.e. the kernel is bound by vector ALU work, see roofline_valu"},
+            "roofline_valu": {"bound": "fp32-valu", "achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach_tf / VALU_PEAK_TFLOPS, "algorithmic_flops_per_sample": flops_ps},
+            "work_per_sample": {k: cnt[k] / max(cnt["path_samples"], 1) for k in cnt if k != "path_samples"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            base = cpu_baseline(scene, cam, W, H, 42)
+            if base is not None:
+                result["cpu_baseline"] = base
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
