@@ -11,27 +11,20 @@
 //   traceRaysKernel      one lane per caller-supplied ray
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <vector>
 
 #include "pt_amd.h"
 #include "pt_device.hpp"
 #include "pt_internal.hpp"
+#include "pt_scene_host.hpp"
 
 using namespace ptd;
 using ptint::fail;
 
 namespace {
-
-struct RenderArgs {
-    pt_camera cam;
-    pt_render_params p;
-    int x0, y0, tw, th; // tile origin and size
-    int s0, s1;         // sample range
-    PathParams pp;
-};
 
 // pixel of the tile handled by this lane: 8x8 pixels per wave, 16x16 per 256-thread block
 PT_DEV bool lanePixel(const RenderArgs& a, int& x, int& y)
@@ -160,54 +153,7 @@ __global__ void __launch_bounds__(256) traceRaysKernel(DevScene sc, uint64_t n, 
 
 // ------------------------------------------------------------------- host --
 
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess)
-            prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0)
-            (void)hipSetDevice(prev);
-    }
-};
-
-template <typename T>
-int upload(const T* host, size_t count, T** dev, std::vector<void*>& owned)
-{
-    *dev = nullptr;
-    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, bytes));
-    owned.push_back(p);
-    if (count > 0)
-        HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
-    *dev = static_cast<T*>(p);
-    return PT_OK;
-}
-
 } // namespace
-
-struct pt_scene {
-    int device = 0;
-    DevScene dev;
-    std::vector<void*> owned; // every device allocation of the scene
-    float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
-    uint64_t n_surfaces = 0;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
-    bool timed = false;
-};
 
 namespace {
 
@@ -280,7 +226,15 @@ int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_
     return PT_OK;
 }
 
-int launchRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream, unsigned long long* d_counters)
+bool useMegakernel()
+{
+    const char* v = std::getenv("PT_RENDERER");
+    return v && std::strcmp(v, "mega") == 0;
+}
+
+// The per-pixel megakernel: kept for instrumentation (work counters) and as the
+// comparison point for the wavefront renderer.
+int launchMegakernel(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream, unsigned long long* d_counters)
 {
     if (a.tw == 0 || a.th == 0)
         return PT_OK;
@@ -295,6 +249,13 @@ int launchRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t
     HIP_TRY(hipEventRecord(scene->evStop, stream));
     scene->timed = true;
     return PT_OK;
+}
+
+int launchRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream, unsigned long long* d_counters)
+{
+    if (d_counters || useMegakernel())
+        return launchMegakernel(scene, a, d_out, stream, d_counters);
+    return ptWavefrontRender(scene, a, d_out, stream);
 }
 
 } // namespace
@@ -314,6 +275,7 @@ void pt_scene_destroy(pt_scene* scene)
     if (!scene)
         return;
     DeviceGuard g(scene->device);
+    ptWavefrontRelease(scene);
     for (void* p : scene->owned)
         (void)hipFree(p);
     if (scene->evStart)
@@ -583,6 +545,8 @@ int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_
     if (n > (uint64_t(1) << 31))
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
     DeviceGuard g(scene->device);
+    if (!useMegakernel())
+        return ptWavefrontSamples(scene, a, out_rgb_per_sample);
     float* d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * 3 * sizeof(float)));
     hipLaunchKernelGGL(renderSamplesKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, a, n, d_out);

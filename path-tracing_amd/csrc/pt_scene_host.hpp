@@ -1,0 +1,88 @@
+// pt_scene_host.hpp -- host-side state of a device-resident scene, shared by the
+// translation units that implement the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "pt_amd.h"
+#include "pt_device.hpp"
+#include "pt_internal.hpp"
+
+struct RenderArgs {
+    pt_camera cam;
+    pt_render_params p;
+    int x0, y0, tw, th; // tile origin and size
+    int s0, s1;         // sample range
+    ptd::PathParams pp;
+};
+
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return ptint::fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+int upload(const T* host, size_t count, T** dev, std::vector<void*>& owned)
+{
+    *dev = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    owned.push_back(p);
+    if (count > 0)
+        HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T*>(p);
+    return PT_OK;
+}
+
+
+// Work areas of the wavefront renderer, allocated on first use and kept.
+struct WavefrontBuffers {
+    void* pool = nullptr;       // path-state arrays, nSlots each
+    uint32_t nSlots = 0;
+    float* samples = nullptr;   // per-sample radiance of one batch
+    uint64_t sampleCapacity = 0; // in samples (3 floats each)
+    float* accum = nullptr;     // running per-pixel sums across batches
+    uint64_t accumCapacity = 0; // in pixels
+    uint32_t* counters = nullptr;
+    uint32_t* hostCounters = nullptr; // pinned
+};
+
+struct pt_scene {
+    int device = 0;
+    ptd::DevScene dev;
+    std::vector<void*> owned; // every device allocation of the scene
+    float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
+    uint64_t n_surfaces = 0;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+    WavefrontBuffers wf;
+};
+
+
+// pt_wavefront.hip
+int ptWavefrontRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);
+int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out_pixel_major);
+void ptWavefrontRelease(pt_scene* scene);

@@ -1,0 +1,534 @@
+// pt_wavefront.hip -- the wavefront renderer: generate / trace / shade kernels
+// over a pool of path slots in HBM, plus the resolve kernel.
+//
+// One path = one (pixel, sample).  A fixed pool of path slots lives in HBM as
+// structure-of-arrays of 16-byte records; every iteration of the host loop runs
+//
+//   generateKernel  slots without a path draw the next path number from a global
+//                   counter (one atomic per wave), compute the camera ray and
+//                   reset the path state (reference src/15/pathtracer.cpp:202-215,
+//                   camera.hpp:34-55);
+//   traceKernel     one lane per live slot: closest hit of its ray (reference
+//                   src/15/bvh.hpp:183-213); then one lane per queued shadow ray:
+//                   closest hit, and if it is the chosen light, add the prepared
+//                   contribution (reference src/15/pathtracer.cpp:99-107);
+//   shadeKernel     one lane per live slot: environment on a miss, else hit
+//                   record, scatter, emission, light pdfs, light sample, MIS,
+//                   Russian roulette (reference src/15/pathtracer.cpp:60-126);
+//                   queues the shadow ray with a wave-wide ballot + prefix sum;
+//                   a finished path writes its radiance to the sample buffer.
+//
+// Finished radiances go to a sample buffer indexed [sample][pixel]; resolveKernel
+// then adds each pixel's samples in sample order -- the same sequence of float
+// additions as the reference's accumulation loop (src/15/pathtracer.cpp:207-220),
+// which keeps the image bit-identical to a sequential evaluation however the
+// paths were scheduled.  All arithmetic per path is that of pt_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "pt_scene_host.hpp"
+
+using namespace ptd;
+using ptint::fail;
+
+namespace {
+
+enum : uint32_t { kNeed = 0, kActive = 1, kDone = 2 };
+
+struct Pool {
+    float4* o_t;   // ray origin, time
+    float4* d_s;   // ray direction, bits: state << 16 | segment
+    uint4* hit;    // surface | backside << 31, bits a, bits u, bits v
+    float4* thr_n; // throughput, bits: number of random draws made
+    float4* rad_p; // radiance so far, bits: index of the path in the sample buffer
+    uint2* key;    // generator key of the path
+    float4* sh_o;  // shadow ray queue: origin, time
+    float4* sh_d;  //   direction, bits: destination (slot or sample-buffer index)
+    float4* sh_c;  //   contribution, bits: light surface | destination-is-sample << 31
+    uint32_t nSlots;
+};
+
+// geometry of one batch of paths
+struct Batch {
+    uint32_t tilesX, tilesY; // 8x8 pixel tiles covering the tile rectangle
+    uint32_t nS;             // samples per pixel in this batch
+    uint32_t sFirst;         // first sample index of the batch
+    uint32_t npix;           // pixels of the tile rectangle
+    uint32_t totalIds;       // tilesX * tilesY * 64 * nS
+};
+
+// counters[0] next path number, [1] finished paths, [2], [3] shadow queue fill (double buffered)
+
+PT_DEV uint32_t laneId() { return __lane_id(); }
+
+// rank of this lane among the lanes of `mask` and the wave-wide base obtained by one atomicAdd
+PT_DEV uint32_t waveReserve(uint32_t* counter, bool want, uint64_t& mask)
+{
+    mask = __ballot(want);
+    if (mask == 0)
+        return 0;
+    const uint32_t lane = laneId();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (int(lane) == leader)
+        base = atomicAdd(counter, uint32_t(__popcll(mask)));
+    base = __shfl(base, leader);
+    return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+__global__ void __launch_bounds__(256) generateKernel(Pool pool, RenderArgs a, Batch b, uint32_t* __restrict__ counters,
+                                                      int parity)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot == 0)
+        counters[2 + parity] = 0; // the queue this iteration's shadeKernel will fill
+    if (slot >= pool.nSlots)
+        return;
+    float4 d_s = pool.d_s[slot];
+    const bool need = ((fbits(d_s.w) >> 16) & 3u) == kNeed;
+    uint64_t mask;
+    const uint32_t id = waveReserve(&counters[0], need, mask);
+    if (!need)
+        return;
+    if (id >= b.totalIds) {
+        d_s.w = __uint_as_float(kDone << 16);
+        pool.d_s[slot] = d_s;
+        return;
+    }
+    // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
+    const uint32_t group = id >> 6, inTile = id & 63u;
+    const uint32_t tile = group / b.nS, sLocal = group % b.nS;
+    const int lx = int((tile % b.tilesX) * 8u + (inTile & 7u));
+    const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
+    if (lx >= a.tw || ly >= a.th)
+        return; // padding of an edge tile: not a path; the slot draws again next iteration
+    const int x = a.x0 + lx, y = a.y0 + ly;
+    const int smp = int(b.sFirst + sLocal);
+    Rng<false> rng;
+    rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
+    rng.n = 0;
+    rng.cnt = nullptr;
+    Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+    pool.o_t[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
+    pool.d_s[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
+    pool.thr_n[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
+    pool.rad_p[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sLocal * b.npix + uint32_t(ly * a.tw + lx)));
+    pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
+}
+
+// material and backside flag of an accepted hit, as the emission lookup needs them
+// (reference src/15/surface_triangle.hpp:175, surface_sphere.hpp:29-36)
+PT_DEV void hitMaterial(const DevScene& sc, const Ray& ray, const HitLite& h, int& material, bool& backside)
+{
+    float4 r0 = sc.surf[3 * size_t(h.sid) + 0];
+    float4 r1 = sc.surf[3 * size_t(h.sid) + 1];
+    if (fbits(r0.w) <= kTriDynamic) {
+        material = sc.meshes[fbits(r1.w)].material;
+        backside = h.backside;
+    } else {
+        V3 c;
+        float r;
+        Xform T;
+        uint32_t sphereId;
+        sphereCR(sc, h.sid, ray.time, c, r, T, sphereId);
+        V3 n = normalize(rayAt(ray, h.a) - c);
+        backside = dot(n, -ray.direction) < 0.0f;
+        material = sc.spheres[sphereId].material;
+    }
+}
+
+__global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters, int parity,
+                                                   float* __restrict__ samples)
+{
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    if (item < pool.nSlots) {
+        const float4 d_s = pool.d_s[item];
+        if (((fbits(d_s.w) >> 16) & 3u) != kActive)
+            return;
+        const float4 o_t = pool.o_t[item];
+        Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+        HitLite h = closestHit<false>(sc, ray, 0.0001f, kFltMax, nullptr);
+        pool.hit[item] = make_uint4(h.sid == PT_NO_HIT ? PT_NO_HIT : (h.sid | (h.backside ? 0x80000000u : 0u)),
+                                    fbits(h.a), fbits(h.u), fbits(h.v));
+        return;
+    }
+    const uint32_t k = item - pool.nSlots;
+    if (k >= counters[2 + (parity ^ 1)])
+        return;
+    const float4 so = pool.sh_o[k], sd = pool.sh_d[k], scn = pool.sh_c[k];
+    Ray ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
+    HitLite h = closestHit<false>(sc, ray, 0.0001f, kFltMax, nullptr);
+    const uint32_t lightSurf = fbits(scn.w) & 0x7FFFFFFFu;
+    if (h.sid == PT_NO_HIT || h.sid != lightSurf)
+        return;
+    int lmat;
+    bool lback;
+    hitMaterial(sc, ray, h, lmat, lback);
+    V3 add = v3(scn.x, scn.y, scn.z) * materialLe(sc, lmat, lback);
+    const uint32_t dest = fbits(sd.w);
+    if (fbits(scn.w) & 0x80000000u) {
+        float* p = samples + 3 * size_t(dest);
+        p[0] = p[0] + add.x;
+        p[1] = p[1] + add.y;
+        p[2] = p[2] + add.z;
+    } else {
+        float4 r = pool.rad_p[dest];
+        r.x = r.x + add.x;
+        r.y = r.y + add.y;
+        r.z = r.z + add.z;
+        pool.rad_p[dest] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathParams pp, uint32_t* __restrict__ counters,
+                                                   int parity, float* __restrict__ samples)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    bool active = false;
+    float4 d_s;
+    if (slot < pool.nSlots) {
+        d_s = pool.d_s[slot];
+        active = ((fbits(d_s.w) >> 16) & 3u) == kActive;
+    }
+    bool finished = false;
+    bool haveShadow = false;
+    V3 shOrigin, shDir, shC;
+    float shTime = 0.0f;
+    uint32_t shLight = 0;
+    V3 radiance = v3(0.0f);
+    uint32_t pathLocal = 0;
+
+    if (active) {
+        const float4 o_t = pool.o_t[slot];
+        const uint4 hw = pool.hit[slot];
+        const float4 thr_n = pool.thr_n[slot];
+        const float4 rad_p = pool.rad_p[slot];
+        const uint2 kw = pool.key[slot];
+        const int segment = int(fbits(d_s.w) & 0xFFFFu);
+        Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+        V3 throughput = v3(thr_n.x, thr_n.y, thr_n.z);
+        radiance = v3(rad_p.x, rad_p.y, rad_p.z);
+        pathLocal = fbits(rad_p.w);
+        Rng<false> rng;
+        rng.key = uint64_t(kw.x) | (uint64_t(kw.y) << 32);
+        rng.n = fbits(thr_n.w);
+        rng.cnt = nullptr;
+
+        // one turn of the loop of pathSample, reference src/15/pathtracer.cpp:59-127
+        if (hw.x == PT_NO_HIT) {
+            if (sc.envmap.type != PT_ENV_NONE)
+                radiance = radiance + throughput * envmapValue(sc, ray.direction);
+            finished = true;
+        } else {
+            HitLite hl;
+            hl.sid = hw.x & 0x7FFFFFFFu;
+            hl.backside = (hw.x >> 31) != 0;
+            hl.a = __uint_as_float(hw.y);
+            hl.u = __uint_as_float(hw.z);
+            hl.v = __uint_as_float(hw.w);
+            Hit hr = makeHit(sc, ray, hl);
+            Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng);
+            radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
+            if (sr.type == ScatterNone) {
+                finished = true;
+            } else {
+                V3 nextThroughput = throughput * sr.attenuation / sr.p;
+                if (sr.type == ScatterRandom && sc.n_lights > 0) {
+                    float lightsP = lightsPdf<false>(sc, hr.position, sr.direction, ray.time, nullptr);
+                    nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
+                    uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
+                    if (lightIndex >= sc.n_lights)
+                        lightIndex = sc.n_lights - 1;
+                    const uint32_t lightSurf = sc.lights[lightIndex];
+                    V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
+                    float lightDirP = lightsPdf<false>(sc, hr.position, lightDir, ray.time, nullptr);
+                    if (lightDirP > 0.0f) {
+                        Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
+                        if (lightSR.p > 0.0f) {
+                            float weight = powerHeuristicMIS(lightDirP, lightSR.p);
+                            // everything of the contribution but the light's emission, which
+                            // the shadow ray's hit decides
+                            shC = throughput * lightSR.attenuation / lightDirP * weight;
+                            shOrigin = hr.position;
+                            shDir = lightDir;
+                            shTime = ray.time;
+                            shLight = lightSurf;
+                            haveShadow = true;
+                        }
+                    }
+                }
+                throughput = nextThroughput;
+                ray = makeRay(hr.position, sr.direction, ray.time);
+                float maxT = max_(throughput.x, max_(throughput.y, throughput.z));
+                if (maxT < 1.0f && segment >= pp.rrStart) {
+                    float q = 1.0f - maxT;
+                    if (q > 0.95f)
+                        q = 0.95f;
+                    if (rng.in01() < q) {
+                        finished = true;
+                    } else {
+                        float rrWeight = 1.0f / (1.0f - q);
+                        throughput = throughput * rrWeight;
+                    }
+                }
+                if (segment + 1 >= pp.maxSegments)
+                    finished = true;
+            }
+        }
+        if (finished) {
+            float* p = samples + 3 * size_t(pathLocal);
+            p[0] = radiance.x;
+            p[1] = radiance.y;
+            p[2] = radiance.z;
+            d_s.w = __uint_as_float(kNeed << 16);
+            pool.d_s[slot] = d_s;
+        } else {
+            pool.o_t[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
+            pool.d_s[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z,
+                                         __uint_as_float((kActive << 16) | uint32_t(segment + 1)));
+            pool.thr_n[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.n));
+            pool.rad_p[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(pathLocal));
+        }
+    }
+
+    // queue the shadow ray: one atomic per wave, lanes ranked by a prefix count over the ballot
+    uint64_t mask;
+    const uint32_t pos = waveReserve(&counters[2 + parity], haveShadow, mask);
+    if (haveShadow) {
+        pool.sh_o[pos] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
+        pool.sh_d[pos] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : slot));
+        pool.sh_c[pos] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? 0x80000000u : 0u)));
+    }
+    // count finished paths: one atomic per wave
+    const uint64_t fmask = __ballot(finished);
+    if (fmask != 0 && int(laneId()) == __ffsll((long long)fmask) - 1)
+        atomicAdd(&counters[1], uint32_t(__popcll(fmask)));
+}
+
+// Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
+__global__ void __launch_bounds__(256) resolveKernel(const float* __restrict__ samples, float* __restrict__ accum,
+                                                     float* __restrict__ out, RenderArgs a, Batch b, int firstBatch,
+                                                     int lastBatch)
+{
+    const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
+    if (pix >= b.npix)
+        return;
+    V3 acc = v3(0.0f);
+    if (!firstBatch)
+        acc = v3(accum[3 * size_t(pix) + 0], accum[3 * size_t(pix) + 1], accum[3 * size_t(pix) + 2]);
+    for (uint32_t s = 0; s < b.nS; s++) {
+        const float* p = samples + 3 * (size_t(s) * b.npix + pix);
+        acc = acc + v3(p[0], p[1], p[2]);
+    }
+    if (lastBatch) {
+        if (!(a.p.flags & PT_RENDER_SUM_ONLY))
+            acc = acc / float(a.p.sqrt_spp * a.p.sqrt_spp);
+        const int x = a.x0 + int(pix % uint32_t(a.tw)), y = a.y0 + int(pix / uint32_t(a.tw));
+        float* o = out + 3 * (size_t(y) * a.p.width + x);
+        o[0] = acc.x;
+        o[1] = acc.y;
+        o[2] = acc.z;
+    } else {
+        accum[3 * size_t(pix) + 0] = acc.x;
+        accum[3 * size_t(pix) + 1] = acc.y;
+        accum[3 * size_t(pix) + 2] = acc.z;
+    }
+}
+
+uint64_t envU64(const char* name, uint64_t dflt)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v)
+        return dflt;
+    return std::strtoull(v, nullptr, 10);
+}
+
+size_t poolBytes(uint32_t n)
+{
+    return size_t(n) * (16 * 5 + 8 + 16 * 3);
+}
+
+Pool carvePool(void* base, uint32_t n)
+{
+    Pool p;
+    char* c = static_cast<char*>(base);
+    auto take = [&](size_t bytes) {
+        void* r = c;
+        c += bytes;
+        return r;
+    };
+    p.o_t = static_cast<float4*>(take(size_t(n) * 16));
+    p.d_s = static_cast<float4*>(take(size_t(n) * 16));
+    p.hit = static_cast<uint4*>(take(size_t(n) * 16));
+    p.thr_n = static_cast<float4*>(take(size_t(n) * 16));
+    p.rad_p = static_cast<float4*>(take(size_t(n) * 16));
+    p.sh_o = static_cast<float4*>(take(size_t(n) * 16));
+    p.sh_d = static_cast<float4*>(take(size_t(n) * 16));
+    p.sh_c = static_cast<float4*>(take(size_t(n) * 16));
+    p.key = static_cast<uint2*>(take(size_t(n) * 8));
+    p.nSlots = n;
+    return p;
+}
+
+int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npix)
+{
+    WavefrontBuffers& w = sc->wf;
+    if (w.nSlots < nSlots) {
+        if (w.pool)
+            (void)hipFree(w.pool);
+        w.pool = nullptr;
+        w.nSlots = 0;
+        HIP_TRY(hipMalloc(&w.pool, poolBytes(nSlots)));
+        w.nSlots = nSlots;
+    }
+    if (w.sampleCapacity < nSamples) {
+        if (w.samples)
+            (void)hipFree(w.samples);
+        w.samples = nullptr;
+        w.sampleCapacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.samples), nSamples * 3 * sizeof(float)));
+        w.sampleCapacity = nSamples;
+    }
+    if (w.accumCapacity < npix) {
+        if (w.accum)
+            (void)hipFree(w.accum);
+        w.accum = nullptr;
+        w.accumCapacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.accum), npix * 3 * sizeof(float)));
+        w.accumCapacity = npix;
+    }
+    if (!w.counters)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), 8 * sizeof(uint32_t)));
+    if (!w.hostCounters)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), 8 * sizeof(uint32_t)));
+    return PT_OK;
+}
+
+// Run one batch of samples [sFirst, sFirst + nS) of every pixel of the tile into the sample buffer.
+int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream)
+{
+    WavefrontBuffers& w = sc->wf;
+    HIP_TRY(hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
+    const uint32_t target = b.npix * b.nS;
+    const dim3 block(256);
+    const dim3 gridSlots((pool.nSlots + 255u) / 256u);
+    const dim3 gridTrace((2u * pool.nSlots + 255u) / 256u);
+    const uint64_t maxIters = (uint64_t(b.totalIds) / pool.nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
+    const int checkEvery = 16;
+    uint64_t iter = 0;
+    for (;;) {
+        for (int k = 0; k < checkEvery; k++, iter++) {
+            const int parity = int(iter & 1);
+            hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
+            hipLaunchKernelGGL(traceKernel, gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples);
+            hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (w.hostCounters[1] >= target)
+            break;
+        if (iter > maxIters)
+            return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
+    }
+    // shadow rays queued by the last shadeKernel of a finished path still have to be traced
+    {
+        const int parity = int(iter & 1);
+        hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
+        hipLaunchKernelGGL(traceKernel, gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples);
+        HIP_TRY(hipGetLastError());
+    }
+    return PT_OK;
+}
+
+int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t stream, bool keepSamples)
+{
+    const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
+    const uint32_t nsTotal = uint32_t(a.s1 - a.s0);
+    if (npix == 0 || nsTotal == 0)
+        return PT_OK;
+    const uint32_t tilesX = uint32_t(a.tw + 7) / 8u, tilesY = uint32_t(a.th + 7) / 8u;
+    const uint64_t idsPerSample = uint64_t(tilesX) * tilesY * 64u;
+    // samples per batch: bounded by the sample-buffer budget and by 32-bit path numbers
+    const uint64_t budgetBytes = envU64("PT_SAMPLE_BUFFER_MB", 32768) << 20;
+    uint64_t perBatch = std::max<uint64_t>(1, budgetBytes / (npix * 12));
+    perBatch = std::min<uint64_t>(perBatch, (0xFFFFFFFFull - (1ull << 24)) / idsPerSample);
+    if (perBatch == 0)
+        return fail(PT_ERR_LIMIT, "tile too large for the wavefront renderer");
+    perBatch = std::min<uint64_t>(perBatch, nsTotal);
+    if (keepSamples && perBatch < nsTotal)
+        return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
+    uint64_t wantSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 21);
+    wantSlots = std::min<uint64_t>(wantSlots, (idsPerSample * perBatch + 255) / 256 * 256);
+    wantSlots = std::max<uint64_t>(wantSlots, 256);
+    int rc = ensureBuffers(sc, uint32_t(wantSlots), npix * perBatch, npix);
+    if (rc != PT_OK)
+        return rc;
+    Pool pool = carvePool(sc->wf.pool, uint32_t(wantSlots));
+    HIP_TRY(hipEventRecord(sc->evStart, stream));
+    for (uint32_t s = 0; s < nsTotal; s += uint32_t(perBatch)) {
+        Batch b;
+        b.tilesX = tilesX;
+        b.tilesY = tilesY;
+        b.nS = std::min<uint32_t>(uint32_t(perBatch), nsTotal - s);
+        b.sFirst = uint32_t(a.s0) + s;
+        b.npix = uint32_t(npix);
+        b.totalIds = uint32_t(idsPerSample * b.nS);
+        rc = runBatch(sc, a, b, pool, stream);
+        if (rc != PT_OK)
+            return rc;
+        if (d_out) {
+            hipLaunchKernelGGL(resolveKernel, dim3((b.npix + 255u) / 256u), dim3(256), 0, stream, sc->wf.samples,
+                               sc->wf.accum, d_out, a, b, s == 0 ? 1 : 0, s + b.nS >= nsTotal ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(sc->evStop, stream));
+    sc->timed = true;
+    return PT_OK;
+}
+
+} // namespace
+
+int ptWavefrontRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream)
+{
+    return renderBatches(scene, a, d_out, stream, false);
+}
+
+// Per-sample radiance in pixel-major, sample-minor order (host buffer).
+int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out)
+{
+    int rc = renderBatches(scene, a, nullptr, nullptr, true);
+    if (rc != PT_OK)
+        return rc;
+    const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
+    const uint64_t ns = uint64_t(a.s1 - a.s0);
+    std::vector<float> tmp(npix * ns * 3);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(tmp.data(), scene->wf.samples, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (uint64_t s = 0; s < ns; s++)
+        for (uint64_t p = 0; p < npix; p++)
+            std::memcpy(h_out + 3 * (p * ns + s), tmp.data() + 3 * (s * npix + p), 12);
+    return PT_OK;
+}
+
+void ptWavefrontRelease(pt_scene* scene)
+{
+    WavefrontBuffers& w = scene->wf;
+    if (w.pool)
+        (void)hipFree(w.pool);
+    if (w.samples)
+        (void)hipFree(w.samples);
+    if (w.accum)
+        (void)hipFree(w.accum);
+    if (w.counters)
+        (void)hipFree(w.counters);
+    if (w.hostCounters)
+        (void)hipHostFree(w.hostCounters);
+    w = WavefrontBuffers();
+}
