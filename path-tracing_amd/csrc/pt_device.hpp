@@ -494,8 +494,9 @@ PT_DEV void sphereCR(const DevScene& sc, uint32_t sid, float time, V3& c, float&
     }
 }
 
-// Surface::hit without the record: triangle or sphere
-template <bool COUNT>
+// Surface::hit without the record: triangle or sphere.  DYN = false promises that the scene
+// has no surface whose pose depends on the ray time (no two-key animation), and drops that code.
+template <bool DYN>
 PT_DEV bool surfaceTest(const DevScene& sc, uint32_t sid, const Ray& ray, float amin, float amax, HitLite& out)
 {
     float4 r0 = sc.surf[3 * size_t(sid) + 0];
@@ -504,7 +505,7 @@ PT_DEV bool surfaceTest(const DevScene& sc, uint32_t sid, const Ray& ray, float 
     if (kind <= kTriDynamic) {
         float4 r2 = sc.surf[3 * size_t(sid) + 2];
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
-        if (kind == kTriDynamic) {
+        if (DYN && kind == kTriDynamic) {
             const DevMesh& m = sc.meshes[fbits(r1.w)];
             Xform T = animationAt<PM>(sc.animations[m.animation], ray.time);
             A = apply(T, A);
@@ -524,7 +525,7 @@ PT_DEV bool surfaceTest(const DevScene& sc, uint32_t sid, const Ray& ray, float 
     }
     V3 c = v3(r0.x, r0.y, r0.z);
     float r = r1.x;
-    if (kind == kSphDynamic) {
+    if (DYN && kind == kSphDynamic) {
         const pt_sphere& q = sc.spheres[fbits(r1.y)];
         Xform T = animationAt<PM>(sc.animations[q.animation], ray.time);
         c = apply(T, c);
@@ -545,39 +546,54 @@ PT_DEV bool surfaceTest(const DevScene& sc, uint32_t sid, const Ray& ray, float 
 // the pre-order array depth-first with an explicit stack, always first child
 // first; the stack top is always the node's `escape` link, so following the
 // links visits exactly the same nodes in the same order with no stack.
-template <bool COUNT>
+//
+// One step of that walk: test node `cur`, test its surface if it is a leaf whose
+// box is hit, and move `cur` on.  The walk is over when cur >= sc.n_nodes.
+template <bool COUNT, bool DYN>
+PT_DEV void traverseStep(const DevScene& sc, const Ray& ray, float amin, float& amax, uint32_t& cur, HitLite& best,
+                         Counters* cnt)
+{
+    float4 n0 = sc.nodes[2 * size_t(cur) + 0];
+    float4 n1 = sc.nodes[2 * size_t(cur) + 1];
+    uint32_t escape = fbits(n1.z);
+    uint32_t leaf = fbits(n1.w);
+    if (COUNT)
+        cnt->nodeVisits++;
+    if (aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax)) {
+        if (leaf != kInner) {
+            if (COUNT)
+                cnt->leafTests++;
+            if (surfaceTest<DYN>(sc, leaf, ray, amin, amax, best))
+                amax = best.a;
+            cur = escape;
+        } else {
+            cur = cur + 1;
+        }
+    } else {
+        cur = escape;
+    }
+}
+
+PT_DEV HitLite noHit()
+{
+    HitLite h;
+    h.sid = PT_NO_HIT;
+    h.a = 0.0f;
+    h.u = h.v = 0.0f;
+    h.backside = false;
+    return h;
+}
+
+template <bool COUNT, bool DYN = true>
 PT_DEV HitLite closestHit(const DevScene& sc, const Ray& ray, float amin, float amax, Counters* cnt)
 {
-    HitLite best;
-    best.sid = PT_NO_HIT;
-    best.a = 0.0f;
-    best.u = best.v = 0.0f;
-    best.backside = false;
+    HitLite best = noHit();
     if (COUNT)
         cnt->rays++;
     uint32_t cur = 0;
     const uint32_t end = sc.n_nodes;
-    while (cur < end) {
-        float4 n0 = sc.nodes[2 * size_t(cur) + 0];
-        float4 n1 = sc.nodes[2 * size_t(cur) + 1];
-        uint32_t escape = fbits(n1.z);
-        uint32_t leaf = fbits(n1.w);
-        if (COUNT)
-            cnt->nodeVisits++;
-        if (aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax)) {
-            if (leaf != kInner) {
-                if (COUNT)
-                    cnt->leafTests++;
-                if (surfaceTest<COUNT>(sc, leaf, ray, amin, amax, best))
-                    amax = best.a;
-                cur = escape;
-            } else {
-                cur = cur + 1;
-            }
-        } else {
-            cur = escape;
-        }
-    }
+    while (cur < end)
+        traverseStep<COUNT, DYN>(sc, ray, amin, amax, cur, best, cnt);
     return best;
 }
 

@@ -320,6 +320,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     }
 
     auto bitsf = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    bool hasDynamic = false;
     std::vector<float4> surf(3 * d->n_surfaces);
     for (uint64_t i = 0; i < d->n_surfaces; i++) {
         const pt_surface& s = d->surfaces[i];
@@ -334,6 +335,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
                 const pt_animation& an = d->animations[m.animation];
                 if (an.type == PT_ANIM_TWOKEY) {
                     kind = kTriDynamic;
+                    hasDynamic = true;
                 } else {
                     // a time-independent pose: apply it once, with the arithmetic of
                     // Transformation::operator* (reference src/15/transformation.hpp:34-37)
@@ -355,6 +357,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
                 const pt_animation& an = d->animations[q.animation];
                 if (an.type == PT_ANIM_TWOKEY) {
                     kind = kSphDynamic;
+                    hasDynamic = true;
                 } else {
                     Xform T = an.type == PT_ANIM_CONSTANT ? xformOf(an.T0) : xformIdentity();
                     c = apply(T, c);
@@ -370,6 +373,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     pt_scene* sc = new pt_scene;
     sc->device = device;
     sc->n_surfaces = d->n_surfaces;
+    sc->hasDynamic = hasDynamic;
     std::memset(&sc->dev, 0, sizeof(sc->dev));
     DevScene& dev = sc->dev;
     auto bail = [&](int code) {

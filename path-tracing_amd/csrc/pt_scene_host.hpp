@@ -78,6 +78,7 @@ struct pt_scene {
     uint64_t n_surfaces = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
+    bool hasDynamic = false; // some surface or sphere has a time-dependent (two-key) pose
     WavefrontBuffers wf;
 };
 

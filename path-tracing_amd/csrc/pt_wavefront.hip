@@ -50,6 +50,7 @@ struct Pool {
     float4* sh_d;  //   direction, bits: destination (slot or sample-buffer index)
     float4* sh_c;  //   contribution, bits: light surface | destination-is-sample << 31
     uint32_t nSlots;
+    uint32_t nShards; // min(8, number of 256-slot blocks): shard of a block = blockIdx % nShards
 };
 
 // geometry of one batch of paths
@@ -61,46 +62,62 @@ struct Batch {
     uint32_t totalIds;       // tilesX * tilesY * 64 * nS
 };
 
-// counters[0] next path number, [1] finished paths, [2], [3] shadow queue fill (double buffered)
+// Counters, one per 128-byte line (word index = id * 32):
+//   0..7   path numbers handed out by shard q (a shard = the blocks with blockIdx % 8 == q)
+//   8      slots that have run out of work
+//   16..23 / 24..31  fill of the shadow-ray queue of shard q, double buffered by iteration parity
+constexpr uint32_t kShards = 8;
+constexpr uint32_t kCtrStride = 32;
+constexpr uint32_t kCtrDone = 8;
+constexpr uint32_t kCtrShadow = 16;
+constexpr uint32_t kCtrWords = 32 * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
-// rank of this lane among the lanes of `mask` and the wave-wide base obtained by one atomicAdd
-PT_DEV uint32_t waveReserve(uint32_t* counter, bool want, uint64_t& mask)
+// Reserve one unit for every thread of the block that wants one: wave ballots, a
+// prefix sum over the four wave counts in LDS, and ONE atomic per block.
+PT_DEV uint32_t blockReserve(uint32_t* counter, bool want, uint32_t* lds /* 5 words */)
 {
-    mask = __ballot(want);
-    if (mask == 0)
-        return 0;
-    const uint32_t lane = laneId();
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (int(lane) == leader)
-        base = atomicAdd(counter, uint32_t(__popcll(mask)));
-    base = __shfl(base, leader);
+    const uint64_t mask = __ballot(want);
+    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    if (lane == 0)
+        lds[wave] = uint32_t(__popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = lds[4];
+    for (uint32_t w = 0; w < wave; w++)
+        base += lds[w];
     return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
 __global__ void __launch_bounds__(256) generateKernel(Pool pool, RenderArgs a, Batch b, uint32_t* __restrict__ counters,
                                                       int parity)
 {
+    __shared__ uint32_t lds[5];
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (slot == 0)
-        counters[2 + parity] = 0; // the queue this iteration's shadeKernel will fill
-    if (slot >= pool.nSlots)
-        return;
+    const uint32_t shard = blockIdx.x % pool.nShards;
+    if (blockIdx.x < kShards && threadIdx.x == 0)
+        counters[(kCtrShadow + parity * kShards + blockIdx.x) * kCtrStride] = 0; // queues this iteration's shadeKernel fills
     float4 d_s = pool.d_s[slot];
     const bool need = ((fbits(d_s.w) >> 16) & 3u) == kNeed;
-    uint64_t mask;
-    const uint32_t id = waveReserve(&counters[0], need, mask);
+    const uint32_t local = blockReserve(&counters[shard * kCtrStride], need, lds);
     if (!need)
         return;
-    if (id >= b.totalIds) {
+    // shard q owns the groups of 64 path numbers g with g % nShards == q
+    const uint32_t group = (local >> 6) * pool.nShards + shard, inTile = local & 63u;
+    if (group >= b.totalIds >> 6) {
         d_s.w = __uint_as_float(kDone << 16);
         pool.d_s[slot] = d_s;
+        const uint64_t m = __ballot(true);
+        if (int(laneId()) == __ffsll((long long)m) - 1)
+            atomicAdd(&counters[kCtrDone * kCtrStride], uint32_t(__popcll(m)));
         return;
     }
     // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
-    const uint32_t group = id >> 6, inTile = id & 63u;
     const uint32_t tile = group / b.nS, sLocal = group % b.nS;
     const int lx = int((tile % b.tilesX) * 8u + (inTile & 7u));
     const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
@@ -141,52 +158,119 @@ PT_DEV void hitMaterial(const DevScene& sc, const Ray& ray, const HitLite& h, in
     }
 }
 
+// Closest-hit tracing of a stream of rays.  Every wave owns a contiguous run of
+// items and keeps its 64 lanes busy: a lane whose ray has finished writes its
+// result and takes the wave's next item, so lanes do not wait for the longest ray
+// of a fixed group of 64.  The hand-out is a ballot and a popcount inside the wave;
+// no memory atomics.
+//   KIND 0: items are path slots (rays of live paths; result = hit record)
+//   KIND 1: items are queued shadow rays (result = contribution added if the chosen light is hit)
+constexpr uint32_t kItemsPerLane = 8;
+constexpr uint32_t kRefillLanes = 16; // refill once this many lanes are idle
+
+template <int KIND, bool DYN>
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters, int parity,
-                                                   float* __restrict__ samples)
+                                                   float* __restrict__ samples, uint32_t shadowCap)
 {
-    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
-    if (item < pool.nSlots) {
-        const float4 d_s = pool.d_s[item];
-        if (((fbits(d_s.w) >> 16) & 3u) != kActive)
-            return;
-        const float4 o_t = pool.o_t[item];
-        Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
-        HitLite h = closestHit<false>(sc, ray, 0.0001f, kFltMax, nullptr);
-        pool.hit[item] = make_uint4(h.sid == PT_NO_HIT ? PT_NO_HIT : (h.sid | (h.backside ? 0x80000000u : 0u)),
-                                    fbits(h.a), fbits(h.u), fbits(h.v));
-        return;
-    }
-    const uint32_t k = item - pool.nSlots;
-    if (k >= counters[2 + (parity ^ 1)])
-        return;
-    const float4 so = pool.sh_o[k], sd = pool.sh_d[k], scn = pool.sh_c[k];
-    Ray ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
-    HitLite h = closestHit<false>(sc, ray, 0.0001f, kFltMax, nullptr);
-    const uint32_t lightSurf = fbits(scn.w) & 0x7FFFFFFFu;
-    if (h.sid == PT_NO_HIT || h.sid != lightSurf)
-        return;
-    int lmat;
-    bool lback;
-    hitMaterial(sc, ray, h, lmat, lback);
-    V3 add = v3(scn.x, scn.y, scn.z) * materialLe(sc, lmat, lback);
-    const uint32_t dest = fbits(sd.w);
-    if (fbits(scn.w) & 0x80000000u) {
-        float* p = samples + 3 * size_t(dest);
-        p[0] = p[0] + add.x;
-        p[1] = p[1] + add.y;
-        p[2] = p[2] + add.z;
+    const uint32_t waveIdx = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t lane = laneId();
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t pos = waveIdx * (64u * kItemsPerLane);
+    uint32_t endPos = pos + 64u * kItemsPerLane;
+    uint32_t itemBase = 0; // KIND 1: first entry of the wave's shard queue
+    if (KIND == 0) {
+        endPos = min(endPos, pool.nSlots);
     } else {
-        float4 r = pool.rad_p[dest];
-        r.x = r.x + add.x;
-        r.y = r.y + add.y;
-        r.z = r.z + add.z;
-        pool.rad_p[dest] = r;
+        // the wave's run lies inside one shard queue (shadowCap is a multiple of the run length)
+        const uint32_t shard = pos / shadowCap;
+        if (shard >= kShards)
+            return;
+        const uint32_t fill = counters[(kCtrShadow + (parity ^ 1) * kShards + shard) * kCtrStride];
+        itemBase = shard * shadowCap;
+        pos -= itemBase;
+        endPos = min(pos + 64u * kItemsPerLane, fill);
+    }
+    if (pos >= endPos)
+        return;
+
+    bool have = false;
+    uint32_t item = 0;
+    Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
+    float amax = 0.0f;
+    uint32_t cur = 0;
+    HitLite best = noHit();
+    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // KIND 1: contribution, bits light | flag
+    uint32_t dest = 0;
+
+    for (;;) {
+        const uint64_t idle = __ballot(!have);
+        const uint32_t nIdle = uint32_t(__popcll(idle));
+        if (nIdle == 64u && pos >= endPos)
+            break;
+        if (pos < endPos && (nIdle >= kRefillLanes || nIdle == 64u)) {
+            const uint32_t cand = pos + uint32_t(__popcll(idle & below));
+            if (!have && cand < endPos) {
+                item = cand;
+                if (KIND == 0) {
+                    const float4 d_s = pool.d_s[item];
+                    if (((fbits(d_s.w) >> 16) & 3u) == kActive) {
+                        const float4 o_t = pool.o_t[item];
+                        ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+                        have = true;
+                    }
+                } else {
+                    const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
+                    payload = pool.sh_c[itemBase + item];
+                    dest = fbits(sd.w);
+                    ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
+                    have = true;
+                }
+                if (have) {
+                    amax = kFltMax;
+                    cur = 0;
+                    best = noHit();
+                }
+            }
+            pos = min(pos + nIdle, endPos);
+        }
+        if (have) {
+            if (cur < sc.n_nodes)
+                traverseStep<false, DYN>(sc, ray, 0.0001f, amax, cur, best, nullptr);
+            if (cur >= sc.n_nodes) {
+                have = false;
+                if (KIND == 0) {
+                    pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
+                                                fbits(best.a), fbits(best.u), fbits(best.v));
+                } else {
+                    const uint32_t lightSurf = fbits(payload.w) & 0x7FFFFFFFu;
+                    if (best.sid != PT_NO_HIT && best.sid == lightSurf) {
+                        int lmat;
+                        bool lback;
+                        hitMaterial(sc, ray, best, lmat, lback);
+                        V3 add = v3(payload.x, payload.y, payload.z) * materialLe(sc, lmat, lback);
+                        if (fbits(payload.w) & 0x80000000u) {
+                            float* p = samples + 3 * size_t(dest);
+                            p[0] = p[0] + add.x;
+                            p[1] = p[1] + add.y;
+                            p[2] = p[2] + add.z;
+                        } else {
+                            float4 r = pool.rad_p[dest];
+                            r.x = r.x + add.x;
+                            r.y = r.y + add.y;
+                            r.z = r.z + add.z;
+                            pool.rad_p[dest] = r;
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathParams pp, uint32_t* __restrict__ counters,
-                                                   int parity, float* __restrict__ samples)
+                                                   int parity, float* __restrict__ samples, uint32_t shadowCap)
 {
+    __shared__ uint32_t lds[5];
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     bool active = false;
     float4 d_s;
@@ -295,18 +379,15 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
         }
     }
 
-    // queue the shadow ray: one atomic per wave, lanes ranked by a prefix count over the ballot
-    uint64_t mask;
-    const uint32_t pos = waveReserve(&counters[2 + parity], haveShadow, mask);
+    // queue the shadow ray in the shard's queue: one atomic per block, lanes ranked by ballots
+    const uint32_t shard = blockIdx.x % pool.nShards;
+    const uint32_t pos = blockReserve(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow, lds);
     if (haveShadow) {
-        pool.sh_o[pos] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
-        pool.sh_d[pos] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : slot));
-        pool.sh_c[pos] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? 0x80000000u : 0u)));
+        const uint32_t e = shard * shadowCap + pos;
+        pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
+        pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : slot));
+        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? 0x80000000u : 0u)));
     }
-    // count finished paths: one atomic per wave
-    const uint64_t fmask = __ballot(finished);
-    if (fmask != 0 && int(laneId()) == __ffsll((long long)fmask) - 1)
-        atomicAdd(&counters[1], uint32_t(__popcll(fmask)));
 }
 
 // Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
@@ -347,9 +428,18 @@ uint64_t envU64(const char* name, uint64_t dflt)
     return std::strtoull(v, nullptr, 10);
 }
 
+// capacity of one shard's shadow queue: the slots of the blocks of that shard, rounded up to whole wave runs
+uint32_t shadowCapOf(uint32_t nSlots)
+{
+    const uint32_t blocks = nSlots / 256u;
+    const uint32_t perShard = (blocks + kShards - 1) / kShards * 256u;
+    const uint32_t run = 64u * kItemsPerLane;
+    return (perShard + run - 1) / run * run;
+}
+
 size_t poolBytes(uint32_t n)
 {
-    return size_t(n) * (16 * 5 + 8 + 16 * 3);
+    return size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * 16 * 3;
 }
 
 Pool carvePool(void* base, uint32_t n)
@@ -366,11 +456,13 @@ Pool carvePool(void* base, uint32_t n)
     p.hit = static_cast<uint4*>(take(size_t(n) * 16));
     p.thr_n = static_cast<float4*>(take(size_t(n) * 16));
     p.rad_p = static_cast<float4*>(take(size_t(n) * 16));
-    p.sh_o = static_cast<float4*>(take(size_t(n) * 16));
-    p.sh_d = static_cast<float4*>(take(size_t(n) * 16));
-    p.sh_c = static_cast<float4*>(take(size_t(n) * 16));
+    const size_t q = size_t(shadowCapOf(n)) * kShards;
+    p.sh_o = static_cast<float4*>(take(q * 16));
+    p.sh_d = static_cast<float4*>(take(q * 16));
+    p.sh_c = static_cast<float4*>(take(q * 16));
     p.key = static_cast<uint2*>(take(size_t(n) * 8));
     p.nSlots = n;
+    p.nShards = std::min<uint32_t>(kShards, n / 256u);
     return p;
 }
 
@@ -402,47 +494,61 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
         w.accumCapacity = npix;
     }
     if (!w.counters)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), 8 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), kCtrWords * sizeof(uint32_t)));
     if (!w.hostCounters)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), 8 * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), kCtrWords * sizeof(uint32_t)));
     return PT_OK;
+}
+
+// Run one batch of samples [sFirst, sFirst + nS) of every pixel of the tile into the sample buffer.
+template <bool DYN>
+void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream, int parity,
+                     bool shade)
+{
+    WavefrontBuffers& w = sc->wf;
+    const dim3 block(256);
+    const dim3 gridSlots(pool.nSlots / 256u);
+    const uint32_t run = 64u * kItemsPerLane;
+    const uint32_t shadowCap = shadowCapOf(pool.nSlots);
+    const dim3 gridTrace(((pool.nSlots + run - 1) / run + 3u) / 4u);
+    const dim3 gridShadow((shadowCap * kShards / run + 3u) / 4u);
+    hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
+    hipLaunchKernelGGL((traceKernel<0, DYN>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples,
+                       shadowCap);
+    hipLaunchKernelGGL((traceKernel<1, DYN>), gridShadow, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples,
+                       shadowCap);
+    if (shade)
+        hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples,
+                           shadowCap);
 }
 
 // Run one batch of samples [sFirst, sFirst + nS) of every pixel of the tile into the sample buffer.
 int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream)
 {
     WavefrontBuffers& w = sc->wf;
-    HIP_TRY(hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
-    const uint32_t target = b.npix * b.nS;
-    const dim3 block(256);
-    const dim3 gridSlots((pool.nSlots + 255u) / 256u);
-    const dim3 gridTrace((2u * pool.nSlots + 255u) / 256u);
     const uint64_t maxIters = (uint64_t(b.totalIds) / pool.nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const int checkEvery = 16;
+    const bool dyn = sc->hasDynamic;
     uint64_t iter = 0;
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
-            const int parity = int(iter & 1);
-            hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
-            hipLaunchKernelGGL(traceKernel, gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples);
-            hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples);
+            if (dyn)
+                launchIteration<true>(sc, a, b, pool, stream, int(iter & 1), true);
+            else
+                launchIteration<false>(sc, a, b, pool, stream, int(iter & 1), true);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (w.hostCounters[1] >= target)
+        if (w.hostCounters[kCtrDone * kCtrStride] >= pool.nSlots)
             break;
         if (iter > maxIters)
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
-    // shadow rays queued by the last shadeKernel of a finished path still have to be traced
-    {
-        const int parity = int(iter & 1);
-        hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
-        hipLaunchKernelGGL(traceKernel, gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples);
-        HIP_TRY(hipGetLastError());
-    }
+    // a slot runs out of work one iteration after its last path finished, so every queued
+    // shadow ray has been traced by now
     return PT_OK;
 }
 
