@@ -14,7 +14,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libptamd.so")
+# PT_AMD_LIB selects another build of the library (used to compare kernel variants)
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "lib", "libptamd.so")
 
 _fp = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)

@@ -360,42 +360,45 @@ struct HitLite {
 };
 
 // AABB::hit, reference src/15/aabb.hpp:41-60.  NaN comparisons are false,
-// exactly as in the reference: a NaN slab neither rejects nor tightens.
+// exactly as in the reference: a NaN slab neither rejects nor tightens.  The
+// reference returns at the first rejecting axis; evaluating all three axes and
+// combining the verdicts gives the same answer without branches.
 PT_DEV bool aabbHit(V3 lo, V3 hi, const Ray& ray, float amin, float amax)
 {
+    bool reject;
     {
         float inv = ray.invDirection.x, org = ray.origin.x;
         bool neg = inv < 0.0f;
         float admin = ((neg ? hi.x : lo.x) - org) * inv;
         float admax = ((neg ? lo.x : hi.x) - org) * inv;
-        if (admin > amax || amin > admax)
-            return false;
-        if (admin > amin)
-            amin = admin;
-        if (admax < amax)
-            amax = admax;
+        reject = (admin > amax) | (amin > admax);
+        amin = admin > amin ? admin : amin;
+        amax = admax < amax ? admax : amax;
     }
     {
         float inv = ray.invDirection.y, org = ray.origin.y;
         bool neg = inv < 0.0f;
         float admin = ((neg ? hi.y : lo.y) - org) * inv;
         float admax = ((neg ? lo.y : hi.y) - org) * inv;
-        if (admin > amax || amin > admax)
-            return false;
-        if (admin > amin)
-            amin = admin;
-        if (admax < amax)
-            amax = admax;
+        reject |= (admin > amax) | (amin > admax);
+        amin = admin > amin ? admin : amin;
+        amax = admax < amax ? admax : amax;
     }
     {
         float inv = ray.invDirection.z, org = ray.origin.z;
         bool neg = inv < 0.0f;
         float admin = ((neg ? hi.z : lo.z) - org) * inv;
         float admax = ((neg ? lo.z : hi.z) - org) * inv;
-        if (admin > amax || amin > admax)
-            return false;
+        reject |= (admin > amax) | (amin > admax);
     }
-    return true;
+    return !reject;
+}
+
+// keep a 16-byte record whole: stops the compiler from splitting the load into
+// pieces fetched one early-out at a time
+PT_DEV void keepWhole(float4& v)
+{
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
 // Moeller-Trumbore, reference src/15/surface_triangle.hpp:101-140
@@ -497,13 +500,14 @@ PT_DEV void sphereCR(const DevScene& sc, uint32_t sid, float time, V3& c, float&
 // Surface::hit without the record: triangle or sphere.  DYN = false promises that the scene
 // has no surface whose pose depends on the ray time (no two-key animation), and drops that code.
 template <bool DYN>
-PT_DEV bool surfaceTest(const DevScene& sc, uint32_t sid, const Ray& ray, float amin, float amax, HitLite& out)
+PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uint32_t sid, const Ray& ray, float amin,
+                        float amax, HitLite& out)
 {
-    float4 r0 = sc.surf[3 * size_t(sid) + 0];
-    float4 r1 = sc.surf[3 * size_t(sid) + 1];
+    float4 r0 = surf[3 * sid + 0];
+    float4 r1 = surf[3 * sid + 1];
     uint32_t kind = fbits(r0.w);
     if (kind <= kTriDynamic) {
-        float4 r2 = sc.surf[3 * size_t(sid) + 2];
+        float4 r2 = surf[3 * sid + 2];
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
         if (DYN && kind == kTriDynamic) {
             const DevMesh& m = sc.meshes[fbits(r1.w)];
@@ -549,12 +553,13 @@ PT_DEV bool surfaceTest(const DevScene& sc, uint32_t sid, const Ray& ray, float 
 //
 // One step of that walk: test node `cur`, test its surface if it is a leaf whose
 // box is hit, and move `cur` on.  The walk is over when cur >= sc.n_nodes.
+// `nodes` and `surf` are the node and surface tables (in HBM, or a copy in LDS).
 template <bool COUNT, bool DYN>
-PT_DEV void traverseStep(const DevScene& sc, const Ray& ray, float amin, float& amax, uint32_t& cur, HitLite& best,
-                         Counters* cnt)
+PT_DEV void traverseStep(const DevScene& sc, const float4* __restrict__ nodes, const float4* __restrict__ surf,
+                         const Ray& ray, float amin, float& amax, uint32_t& cur, HitLite& best, Counters* cnt)
 {
-    float4 n0 = sc.nodes[2 * size_t(cur) + 0];
-    float4 n1 = sc.nodes[2 * size_t(cur) + 1];
+    float4 n0 = nodes[2 * cur + 0];
+    float4 n1 = nodes[2 * cur + 1];
     uint32_t escape = fbits(n1.z);
     uint32_t leaf = fbits(n1.w);
     if (COUNT)
@@ -563,7 +568,7 @@ PT_DEV void traverseStep(const DevScene& sc, const Ray& ray, float amin, float& 
         if (leaf != kInner) {
             if (COUNT)
                 cnt->leafTests++;
-            if (surfaceTest<DYN>(sc, leaf, ray, amin, amax, best))
+            if (surfaceTest<DYN>(sc, surf, leaf, ray, amin, amax, best))
                 amax = best.a;
             cur = escape;
         } else {
@@ -572,6 +577,23 @@ PT_DEV void traverseStep(const DevScene& sc, const Ray& ray, float amin, float& 
     } else {
         cur = escape;
     }
+}
+
+// The node half of a step: test node `cur` and move on; if it is a leaf whose box is hit,
+// report its surface in `pendingLeaf` (the caller must run the surface test -- which may
+// lower amax -- before the next node step, as the reference does).
+PT_DEV void nodeStep(const float4* __restrict__ nodes, const Ray& ray, float amin, float amax, uint32_t& cur,
+                     uint32_t& pendingLeaf)
+{
+    float4 n0 = nodes[2 * cur + 0];
+    float4 n1 = nodes[2 * cur + 1];
+    keepWhole(n0);
+    keepWhole(n1);
+    const uint32_t escape = fbits(n1.z);
+    const uint32_t leaf = fbits(n1.w);
+    const bool hit = aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax);
+    pendingLeaf = hit ? leaf : kInner;
+    cur = (hit && leaf == kInner) ? cur + 1 : escape;
 }
 
 PT_DEV HitLite noHit()
@@ -593,7 +615,7 @@ PT_DEV HitLite closestHit(const DevScene& sc, const Ray& ray, float amin, float 
     uint32_t cur = 0;
     const uint32_t end = sc.n_nodes;
     while (cur < end)
-        traverseStep<COUNT, DYN>(sc, ray, amin, amax, cur, best, cnt);
+        traverseStep<COUNT, DYN>(sc, sc.nodes, sc.surf, ray, amin, amax, cur, best, cnt);
     return best;
 }
 

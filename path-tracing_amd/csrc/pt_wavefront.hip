@@ -49,6 +49,7 @@ struct Pool {
     float4* sh_o;  // shadow ray queue: origin, time
     float4* sh_d;  //   direction, bits: destination (slot or sample-buffer index)
     float4* sh_c;  //   contribution, bits: light surface | destination-is-sample << 31
+    float4* sh_l;  //   emission of the light's front side, bits: 1 = light is a triangle whose back side is black
     uint32_t nSlots;
     uint32_t nShards; // min(8, number of 256-slot blocks): shard of a block = blockIdx % nShards
 };
@@ -165,13 +166,38 @@ PT_DEV void hitMaterial(const DevScene& sc, const Ray& ray, const HitLite& h, in
 // no memory atomics.
 //   KIND 0: items are path slots (rays of live paths; result = hit record)
 //   KIND 1: items are queued shadow rays (result = contribution added if the chosen light is hit)
-constexpr uint32_t kItemsPerLane = 8;
-constexpr uint32_t kRefillLanes = 16; // refill once this many lanes are idle
+#ifndef PT_ITEMS_PER_LANE
+#define PT_ITEMS_PER_LANE 4
+#endif
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 16
+#endif
+#ifndef PT_WALK_LANES
+#define PT_WALK_LANES 32
+#endif
+constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
+constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
+constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
-template <int KIND, bool DYN>
+template <int KIND, bool DYN, bool LDS>
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters, int parity,
                                                    float* __restrict__ samples, uint32_t shadowCap)
 {
+    // small scenes: node and surface tables are copied into LDS once per block, which takes the
+    // per-lane gathers of the walk off the vector memory path
+    extern __shared__ float4 ldsGeo[];
+    const float4* nodes = sc.nodes;
+    const float4* surf = sc.surf;
+    if (LDS) {
+        const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
+        for (uint32_t i = threadIdx.x; i < nNode4; i += 256u)
+            ldsGeo[i] = sc.nodes[i];
+        for (uint32_t i = threadIdx.x; i < nSurf4; i += 256u)
+            ldsGeo[nNode4 + i] = sc.surf[i];
+        __syncthreads();
+        nodes = ldsGeo;
+        surf = ldsGeo + nNode4;
+    }
     const uint32_t waveIdx = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
@@ -198,9 +224,13 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
     Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
     float amax = 0.0f;
     uint32_t cur = 0;
+    uint32_t pending = kInner; // leaf surface whose box was hit and whose test is due
     HitLite best = noHit();
-    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // KIND 1: contribution, bits light | flag
-    uint32_t dest = 0;
+    // KIND 1: what the shadow ray carries
+    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // contribution, bits light | destination-is-sample
+    float4 lightLe = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // emission of the light's front side, bits fast-path flag
+    V3 destValue = v3(0.0f);                              // current value of the accumulator the result is added to
+    uint32_t dest = 0, destW = 0;
 
     for (;;) {
         const uint64_t idle = __ballot(!have);
@@ -221,21 +251,46 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
                 } else {
                     const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
                     payload = pool.sh_c[itemBase + item];
+                    lightLe = pool.sh_l[itemBase + item];
                     dest = fbits(sd.w);
+                    if (fbits(payload.w) & 0x80000000u) {
+                        const float* p = samples + 3 * size_t(dest);
+                        destValue = v3(p[0], p[1], p[2]);
+                    } else {
+                        const float4 r = pool.rad_p[dest];
+                        destValue = v3(r.x, r.y, r.z);
+                        destW = fbits(r.w);
+                    }
                     ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
                     have = true;
                 }
                 if (have) {
                     amax = kFltMax;
                     cur = 0;
+                    pending = kInner;
                     best = noHit();
                 }
             }
             pos = min(pos + nIdle, endPos);
         }
+        // walk: node steps for every lane that still has nodes to visit and no surface waiting,
+        // repeated while enough lanes are walking; then the waiting surfaces are tested together
+        {
+            bool walking = have && pending == kInner && cur < sc.n_nodes;
+            while (__ballot(walking) != 0) {
+                if (walking)
+                    nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
+                walking = have && pending == kInner && cur < sc.n_nodes;
+                if (uint32_t(__popcll(__ballot(walking))) < kWalkLanes)
+                    break;
+            }
+        }
+        if (have && pending != kInner) {
+            if (surfaceTest<DYN>(sc, surf, pending, ray, 0.0001f, amax, best))
+                amax = best.a;
+            pending = kInner;
+        }
         if (have) {
-            if (cur < sc.n_nodes)
-                traverseStep<false, DYN>(sc, ray, 0.0001f, amax, cur, best, nullptr);
             if (cur >= sc.n_nodes) {
                 have = false;
                 if (KIND == 0) {
@@ -244,21 +299,23 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
                 } else {
                     const uint32_t lightSurf = fbits(payload.w) & 0x7FFFFFFFu;
                     if (best.sid != PT_NO_HIT && best.sid == lightSurf) {
-                        int lmat;
-                        bool lback;
-                        hitMaterial(sc, ray, best, lmat, lback);
-                        V3 add = v3(payload.x, payload.y, payload.z) * materialLe(sc, lmat, lback);
+                        V3 le;
+                        if (fbits(lightLe.w) & 1u) {
+                            le = best.backside ? v3(0.0f) : v3(lightLe.x, lightLe.y, lightLe.z);
+                        } else {
+                            int lmat;
+                            bool lback;
+                            hitMaterial(sc, ray, best, lmat, lback);
+                            le = materialLe(sc, lmat, lback);
+                        }
+                        V3 sum = destValue + v3(payload.x, payload.y, payload.z) * le;
                         if (fbits(payload.w) & 0x80000000u) {
                             float* p = samples + 3 * size_t(dest);
-                            p[0] = p[0] + add.x;
-                            p[1] = p[1] + add.y;
-                            p[2] = p[2] + add.z;
+                            p[0] = sum.x;
+                            p[1] = sum.y;
+                            p[2] = sum.z;
                         } else {
-                            float4 r = pool.rad_p[dest];
-                            r.x = r.x + add.x;
-                            r.y = r.y + add.y;
-                            r.z = r.z + add.z;
-                            pool.rad_p[dest] = r;
+                            pool.rad_p[dest] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(destW));
                         }
                     }
                 }
@@ -280,9 +337,9 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
     }
     bool finished = false;
     bool haveShadow = false;
-    V3 shOrigin, shDir, shC;
+    V3 shOrigin, shDir, shC, shLe = v3(0.0f);
     float shTime = 0.0f;
-    uint32_t shLight = 0;
+    uint32_t shLight = 0, shFast = 0;
     V3 radiance = v3(0.0f);
     uint32_t pathLocal = 0;
 
@@ -342,6 +399,16 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
                             shTime = ray.time;
                             shLight = lightSurf;
                             haveShadow = true;
+                            // emission of the chosen light, looked up here so that the tracing
+                            // kernel needs no table reads when the shadow ray arrives
+                            const float4 l0 = sc.surf[3 * size_t(lightSurf) + 0];
+                            if (fbits(l0.w) <= kTriDynamic) {
+                                const float4 l1 = sc.surf[3 * size_t(lightSurf) + 1];
+                                const int lmat = sc.meshes[fbits(l1.w)].material;
+                                shLe = materialLe(sc, lmat, false);
+                                const V3 back = materialLe(sc, lmat, true);
+                                shFast = (back.x == 0.0f && back.y == 0.0f && back.z == 0.0f) ? 1u : 0u;
+                            }
                         }
                     }
                 }
@@ -387,6 +454,7 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
         pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
         pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : slot));
         pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? 0x80000000u : 0u)));
+        pool.sh_l[e] = make_float4(shLe.x, shLe.y, shLe.z, __uint_as_float(shFast));
     }
 }
 
@@ -439,7 +507,7 @@ uint32_t shadowCapOf(uint32_t nSlots)
 
 size_t poolBytes(uint32_t n)
 {
-    return size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * 16 * 3;
+    return size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * 16 * 4;
 }
 
 Pool carvePool(void* base, uint32_t n)
@@ -460,6 +528,7 @@ Pool carvePool(void* base, uint32_t n)
     p.sh_o = static_cast<float4*>(take(q * 16));
     p.sh_d = static_cast<float4*>(take(q * 16));
     p.sh_c = static_cast<float4*>(take(q * 16));
+    p.sh_l = static_cast<float4*>(take(q * 16));
     p.key = static_cast<uint2*>(take(size_t(n) * 8));
     p.nSlots = n;
     p.nShards = std::min<uint32_t>(kShards, n / 256u);
@@ -500,10 +569,12 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
     return PT_OK;
 }
 
-// Run one batch of samples [sFirst, sFirst + nS) of every pixel of the tile into the sample buffer.
-template <bool DYN>
-void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream, int parity,
-                     bool shade)
+// node + surface tables up to this size are traced from LDS
+constexpr size_t kLdsGeoLimit = 16 * 1024;
+
+// generate, trace (path rays), trace (shadow rays), shade: one iteration of the renderer
+template <bool DYN, bool LDS>
+void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream, int parity)
 {
     WavefrontBuffers& w = sc->wf;
     const dim3 block(256);
@@ -512,14 +583,14 @@ void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Po
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
     const dim3 gridTrace(((pool.nSlots + run - 1) / run + 3u) / 4u);
     const dim3 gridShadow((shadowCap * kShards / run + 3u) / 4u);
+    const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
     hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
-    hipLaunchKernelGGL((traceKernel<0, DYN>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples,
+    hipLaunchKernelGGL((traceKernel<0, DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
+                       w.samples, shadowCap);
+    hipLaunchKernelGGL((traceKernel<1, DYN, LDS>), gridShadow, block, lds, stream, sc->dev, pool, w.counters, parity,
+                       w.samples, shadowCap);
+    hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples,
                        shadowCap);
-    hipLaunchKernelGGL((traceKernel<1, DYN>), gridShadow, block, 0, stream, sc->dev, pool, w.counters, parity, w.samples,
-                       shadowCap);
-    if (shade)
-        hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples,
-                           shadowCap);
 }
 
 // Run one batch of samples [sFirst, sFirst + nS) of every pixel of the tile into the sample buffer.
@@ -531,13 +602,19 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool
     const uint64_t maxIters = (uint64_t(b.totalIds) / pool.nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const int checkEvery = 16;
     const bool dyn = sc->hasDynamic;
+    const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
+        && std::getenv("PT_NO_LDS_SCENE") == nullptr;
     uint64_t iter = 0;
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
-            if (dyn)
-                launchIteration<true>(sc, a, b, pool, stream, int(iter & 1), true);
+            if (dyn && lds)
+                launchIteration<true, true>(sc, a, b, pool, stream, int(iter & 1));
+            else if (dyn)
+                launchIteration<true, false>(sc, a, b, pool, stream, int(iter & 1));
+            else if (lds)
+                launchIteration<false, true>(sc, a, b, pool, stream, int(iter & 1));
             else
-                launchIteration<false>(sc, a, b, pool, stream, int(iter & 1), true);
+                launchIteration<false, false>(sc, a, b, pool, stream, int(iter & 1));
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
