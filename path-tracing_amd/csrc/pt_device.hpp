@@ -45,10 +45,18 @@ struct DevMesh {
 // surface id or kInner.  Inner nodes have their first child at index + 1.
 // surf: 3 x float4 per surface; triangles (A.xyz, bits kind), (B.xyz, bits
 // mesh), (C.xyz, bits triangle-in-mesh); spheres (centre.xyz, bits kind),
-// (radius, bits sphere, -, -), unused.
+// (radius, bits sphere, -, -), unused.  surfAttr and matConst repeat, per
+// surface and per material, what shading would otherwise reach through two or
+// three dependent table reads (mesh -> index list -> vertices; material ->
+// texture -> value).
 struct DevScene {
     const float4* nodes;
     const float4* surf;
+    const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24);
+                             // spheres (sphere index, 0, 0, material | flags << 24).  flags: 1 normals,
+                             // 2 texcoords, 4 tangents, 8 mesh has a pose
+    const float4* matConst;  // per material 2 rows: (value of tex[0] if constant, bits mask), (value of tex[1]
+                             // if constant, x of tex[2] if constant); mask bit k = tex[k] is a constant texture
     const float* positions;
     const float* normals;
     const float* texcoords;
@@ -638,17 +646,18 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     hr.a = h.a;
     hr.surface = h.sid;
     hr.position = rayAt(ray, h.a);
+    const uint4 attr = sc.surfAttr[h.sid];
     float4 r0 = sc.surf[3 * size_t(h.sid) + 0];
     float4 r1 = sc.surf[3 * size_t(h.sid) + 1];
     uint32_t kind = fbits(r0.w);
     if (kind <= kTriDynamic) {
         float4 r2 = sc.surf[3 * size_t(h.sid) + 2];
-        const DevMesh& m = sc.meshes[fbits(r1.w)];
-        uint32_t tri = fbits(r2.w);
-        const bool animated = m.animation >= 0;
+        const uint32_t flags = attr.w >> 24;
+        const bool animated = (flags & 8u) != 0;
         Quat rot = Quat{ 0.0f, 0.0f, 0.0f, 1.0f };
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
         if (animated) {
+            const DevMesh& m = sc.meshes[fbits(r1.w)];
             Xform T = animationAt<PM>(sc.animations[m.animation], ray.time);
             rot = T.rotation;
             if (kind == kTriDynamic) {
@@ -657,12 +666,11 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
                 C = apply(T, C);
             }
         }
-        const uint32_t* idx = sc.indices + m.first_index + 3 * size_t(tri);
-        size_t i0 = m.first_vertex + idx[0], i1 = m.first_vertex + idx[1], i2 = m.first_vertex + idx[2];
+        const size_t i0 = attr.x, i1 = attr.y, i2 = attr.z;
         float u = h.u, v = h.v;
         float w = 1.0f - u - v;
         V3 nrm;
-        if (m.flags & 1u) {
+        if (flags & 1u) {
             nrm = w * v3(sc.normals + 3 * i0) + u * v3(sc.normals + 3 * i1) + v * v3(sc.normals + 3 * i2);
             if (animated)
                 nrm = rotate(rot, nrm);
@@ -673,7 +681,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
         if (h.backside)
             nrm = -nrm;
         V2 tc;
-        if (m.flags & 2u) {
+        if (flags & 2u) {
             const float* a = sc.texcoords + 2 * i0;
             const float* b = sc.texcoords + 2 * i1;
             const float* c = sc.texcoords + 2 * i2;
@@ -682,7 +690,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
             tc = V2{ 0.0f, 0.0f };
         }
         V3 tng;
-        if (m.flags & 4u) {
+        if (flags & 4u) {
             tng = w * v3(sc.tangents + 3 * i0) + u * v3(sc.tangents + 3 * i1) + v * v3(sc.tangents + 3 * i2);
             if (animated)
                 tng = rotate(rot, tng);
@@ -697,7 +705,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
         hr.texcoord = tc;
         hr.tangent = tng;
         hr.backside = h.backside;
-        hr.material = m.material;
+        hr.material = int32_t(attr.w & 0xFFFFFFu);
         return hr;
     }
     V3 c;
@@ -723,7 +731,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     hr.texcoord = V2{ u, v };
     hr.tangent = t;
     hr.backside = backside;
-    hr.material = sc.spheres[sphereId].material;
+    hr.material = int32_t(attr.w & 0xFFFFFFu);
     return hr;
 }
 
@@ -747,10 +755,10 @@ __device__ inline V3 surfaceDirection(const DevScene& sc, uint32_t sid, V3 origi
         V3 A, B, C;
         if (m.animation >= 0) {
             // sample the unposed triangle, then pose the point
-            const uint32_t* idx = sc.indices + m.first_index + 3 * size_t(fbits(r2.w));
-            A = v3(sc.positions + 3 * size_t(m.first_vertex + idx[0]));
-            B = v3(sc.positions + 3 * size_t(m.first_vertex + idx[1]));
-            C = v3(sc.positions + 3 * size_t(m.first_vertex + idx[2]));
+            const uint4 attr = sc.surfAttr[sid];
+            A = v3(sc.positions + 3 * size_t(attr.x));
+            B = v3(sc.positions + 3 * size_t(attr.y));
+            C = v3(sc.positions + 3 * size_t(attr.z));
         } else {
             A = v3(r0.x, r0.y, r0.z);
             B = v3(r1.x, r1.y, r1.z);
@@ -890,6 +898,22 @@ __device__ inline V3 phongNormal(const DevScene& sc, const pt_material& m, const
     return n;
 }
 
+// value of texture slot k (0, 1, 2) of material `mid`, skipping the texture tables when the
+// texture is a constant one (resolved at upload)
+PT_DEV V3 materialTexture(const DevScene& sc, int mid, const pt_material& m, int k, V2 tc)
+{
+    const float4 c0 = sc.matConst[2 * mid + 0];
+    if (fbits(c0.w) & (1u << k)) {
+        if (k == 0)
+            return v3(c0.x, c0.y, c0.z);
+        const float4 c1 = sc.matConst[2 * mid + 1];
+        if (k == 1)
+            return v3(c1.x, c1.y, c1.z);
+        return v3(c1.w, c1.w, c1.w); // only the x component of slot 2 is ever used
+    }
+    return textureValue(sc, m.tex[k], tc);
+}
+
 // Material::scatter
 template <bool COUNT>
 __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray& ray, const Hit& hrIn, Rng<COUNT>& rng)
@@ -911,7 +935,7 @@ __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray
         if (cosTheta <= 0.0f)
             return scatterNone();
         float p = cosTheta / kPi;
-        V3 att = (textureValue(sc, m.tex[0], hr.texcoord) / kPi) * cosTheta;
+        V3 att = (materialTexture(sc, mid, m, 0, hr.texcoord) / kPi) * cosTheta;
         return scatterRandom(dir, p, att);
     }
     case PT_MAT_PHONG: { // material_phong.hpp:48-102
@@ -923,9 +947,9 @@ __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray
         }
         if (backside)
             return scatterNone();
-        V3 kd = textureValue(sc, m.tex[0], hr.texcoord);
-        V3 ks = textureValue(sc, m.tex[1], hr.texcoord);
-        float shininess = textureValue(sc, m.tex[2], hr.texcoord).x;
+        V3 kd = materialTexture(sc, mid, m, 0, hr.texcoord);
+        V3 ks = materialTexture(sc, mid, m, 1, hr.texcoord);
+        float shininess = materialTexture(sc, mid, m, 2, hr.texcoord).x;
         V3 n = phongNormal(sc, m, hr);
         V3 v = -ray.direction;
         V3 r = reflect(ray.direction, n);
@@ -963,7 +987,7 @@ __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray
         if (backside)
             return scatterNone();
         V3 dir = normalize(reflect(ray.direction, hr.normal));
-        return scatterExplicit(dir, textureValue(sc, m.tex[0], hr.texcoord));
+        return scatterExplicit(dir, materialTexture(sc, mid, m, 0, hr.texcoord));
     }
     case PT_MAT_GLASS: { // material_glass.hpp:17-49
         V3 att = v3(1.0f);
@@ -1003,7 +1027,7 @@ __device__ inline Scatter materialScatterToDirection(const DevScene& sc, int mid
         if (cosTheta <= 0.0f)
             return scatterNone();
         float p = cosTheta / kPi;
-        V3 att = (textureValue(sc, m.tex[0], hr.texcoord) / kPi) * cosTheta;
+        V3 att = (materialTexture(sc, mid, m, 0, hr.texcoord) / kPi) * cosTheta;
         return scatterRandom(dir, p, att);
     }
     if (m.type == PT_MAT_PHONG) { // material_phong.hpp:104-117
@@ -1012,9 +1036,9 @@ __device__ inline Scatter materialScatterToDirection(const DevScene& sc, int mid
         if (cosTheta <= 0.0f)
             return scatterNone();
         float p = cosTheta / kPi;
-        V3 kd = textureValue(sc, m.tex[0], hr.texcoord);
-        V3 ks = textureValue(sc, m.tex[1], hr.texcoord);
-        float shininess = textureValue(sc, m.tex[2], hr.texcoord).x;
+        V3 kd = materialTexture(sc, mid, m, 0, hr.texcoord);
+        V3 ks = materialTexture(sc, mid, m, 1, hr.texcoord);
+        float shininess = materialTexture(sc, mid, m, 2, hr.texcoord).x;
         V3 att = phongBrdf(n, dir, -ray.direction, kd, ks, shininess) * cosTheta;
         return scatterRandom(dir, p, att);
     }
@@ -1088,11 +1112,10 @@ __device__ inline V3 pathSample(const DevScene& sc, const PathParams& pp, Ray ra
                     if (lh.sid != PT_NO_HIT && lh.sid == lightSurf) {
                         // Le of the light needs only its material and the backside flag
                         float4 r0 = sc.surf[3 * size_t(lh.sid) + 0];
-                        float4 r1 = sc.surf[3 * size_t(lh.sid) + 1];
                         int lmat;
                         bool lback;
                         if (fbits(r0.w) <= kTriDynamic) {
-                            lmat = sc.meshes[fbits(r1.w)].material;
+                            lmat = int(sc.surfAttr[lh.sid].w & 0xFFFFFFu);
                             lback = lh.backside;
                         } else {
                             Hit lhr = makeHit(sc, lightRay, lh);

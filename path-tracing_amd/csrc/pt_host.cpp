@@ -254,8 +254,8 @@ int pt_scene_desc_validate(const pt_scene_desc* d)
         || !need(d->n_materials, d->materials) || !need(d->n_textures, d->textures) || !need(d->n_texels, d->texels)
         || !need(d->n_animations, d->animations) || !need(d->n_bvh_nodes, d->bvh_nodes))
         return fail(PT_ERR_INVALID_ARGUMENT, "scene description has a null array with a non-zero count");
-    if (d->n_surfaces >= 0x7FFFFFFFull || d->n_vertices >= 0xFFFFFFFFull || d->n_indices >= 0xFFFFFFFFull)
-        return fail(PT_ERR_LIMIT, "scene too large for 32-bit surface / vertex ids");
+    if (d->n_surfaces >= 0x3FFFFFFFull || d->n_vertices >= 0xFFFFFFFFull || d->n_indices >= 0xFFFFFFFFull)
+        return fail(PT_ERR_LIMIT, "scene too large: surface ids have 30 bits, vertex ids 32");
 
     for (uint64_t i = 0; i < d->n_animations; i++)
         if (d->animations[i].type < PT_ANIM_IDENTITY || d->animations[i].type > PT_ANIM_TWOKEY)

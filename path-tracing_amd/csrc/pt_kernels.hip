@@ -322,6 +322,9 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     auto bitsf = [](uint32_t u) { return __builtin_bit_cast(float, u); };
     bool hasDynamic = false;
     std::vector<float4> surf(3 * d->n_surfaces);
+    std::vector<uint4> surfAttr(d->n_surfaces);
+    if (d->n_materials >= (1u << 24))
+        return fail(PT_ERR_LIMIT, "more than 2^24 materials");
     for (uint64_t i = 0; i < d->n_surfaces; i++) {
         const pt_surface& s = d->surfaces[i];
         if (s.type == PT_SURF_TRIANGLE) {
@@ -348,6 +351,10 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
             surf[3 * i + 0] = make_float4(A.x, A.y, A.z, bitsf(kind));
             surf[3 * i + 1] = make_float4(B.x, B.y, B.z, bitsf(s.owner));
             surf[3 * i + 2] = make_float4(C.x, C.y, C.z, bitsf(s.index));
+            const uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
+                | (m.animation >= 0 ? 8u : 0u);
+            surfAttr[i] = make_uint4(m.first_vertex + idx[0], m.first_vertex + idx[1], m.first_vertex + idx[2],
+                                     uint32_t(m.material) | (flags << 24));
         } else {
             const pt_sphere& q = d->spheres[s.owner];
             V3 c = v3(q.center);
@@ -367,7 +374,26 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
             surf[3 * i + 0] = make_float4(c.x, c.y, c.z, bitsf(kind));
             surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, 0.0f);
             surf[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material));
         }
+    }
+
+    // constant textures of the first three texture slots, resolved once
+    std::vector<float4> matConst(2 * d->n_materials);
+    for (uint64_t i = 0; i < d->n_materials; i++) {
+        const pt_material& m = d->materials[i];
+        uint32_t mask = 0;
+        float c[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+        const int slots = m.type == PT_MAT_PHONG ? 3 : ((m.type == PT_MAT_LAMBERTIAN || m.type == PT_MAT_MIRROR) ? 1 : 0);
+        for (int k = 0; k < slots; k++) {
+            if (m.tex[k] >= 0 && d->textures[m.tex[k]].type == PT_TEX_CONSTANT) {
+                mask |= 1u << k;
+                for (int j = 0; j < 3; j++)
+                    c[k][j] = d->textures[m.tex[k]].v[j];
+            }
+        }
+        matConst[2 * i + 0] = make_float4(c[0][0], c[0][1], c[0][2], bitsf(mask));
+        matConst[2 * i + 1] = make_float4(c[1][0], c[1][1], c[1][2], c[2][0]);
     }
 
     pt_scene* sc = new pt_scene;
@@ -382,6 +408,8 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     };
     float4* dNodes = nullptr;
     float4* dSurf = nullptr;
+    uint4* dSurfAttr = nullptr;
+    float4* dMatConst = nullptr;
     float *dPos = nullptr, *dNrm = nullptr, *dTc = nullptr, *dTng = nullptr, *dTexels = nullptr;
     uint32_t *dIdx = nullptr, *dLights = nullptr;
     DevMesh* dMeshes = nullptr;
@@ -391,6 +419,8 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     pt_animation* dAnims = nullptr;
     if ((rc = upload(nodes.data(), nodes.size(), &dNodes, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(surf.data(), surf.size(), &dSurf, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(surfAttr.data(), surfAttr.size(), &dSurfAttr, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(matConst.data(), matConst.size(), &dMatConst, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->positions, 3 * d->n_vertices, &dPos, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->normals, 3 * d->n_vertices, &dNrm, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->texcoords, 2 * d->n_vertices, &dTc, sc->owned)) != PT_OK) return bail(rc);
@@ -406,6 +436,8 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     sc->nodes = dNodes;
     dev.nodes = dNodes;
     dev.surf = dSurf;
+    dev.surfAttr = dSurfAttr;
+    dev.matConst = dMatConst;
     dev.positions = dPos;
     dev.normals = dNrm;
     dev.texcoords = dTc;

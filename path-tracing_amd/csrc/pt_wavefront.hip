@@ -38,6 +38,9 @@ using ptint::fail;
 namespace {
 
 enum : uint32_t { kNeed = 0, kActive = 1, kDone = 2 };
+constexpr uint32_t kDestIsSample = 0x80000000u;
+constexpr uint32_t kBackEmits = 0x40000000u;
+constexpr uint32_t kLightMask = 0x3FFFFFFFu;
 
 struct Pool {
     float4* o_t;   // ray origin, time
@@ -48,8 +51,9 @@ struct Pool {
     uint2* key;    // generator key of the path
     float4* sh_o;  // shadow ray queue: origin, time
     float4* sh_d;  //   direction, bits: destination (slot or sample-buffer index)
-    float4* sh_c;  //   contribution, bits: light surface | destination-is-sample << 31
-    float4* sh_l;  //   emission of the light's front side, bits: 1 = light is a triangle whose back side is black
+    float4* sh_c;  //   what to add if the ray reaches the front side of the chosen light, bits: light
+                   //   surface | kBackEmits | kDestIsSample
+    float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
     uint32_t nSlots;
     uint32_t nShards; // min(8, number of 256-slot blocks): shard of a block = blockIdx % nShards
 };
@@ -138,34 +142,18 @@ __global__ void __launch_bounds__(256) generateKernel(Pool pool, RenderArgs a, B
     pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
 }
 
-// material and backside flag of an accepted hit, as the emission lookup needs them
-// (reference src/15/surface_triangle.hpp:175, surface_sphere.hpp:29-36)
-PT_DEV void hitMaterial(const DevScene& sc, const Ray& ray, const HitLite& h, int& material, bool& backside)
-{
-    float4 r0 = sc.surf[3 * size_t(h.sid) + 0];
-    float4 r1 = sc.surf[3 * size_t(h.sid) + 1];
-    if (fbits(r0.w) <= kTriDynamic) {
-        material = sc.meshes[fbits(r1.w)].material;
-        backside = h.backside;
-    } else {
-        V3 c;
-        float r;
-        Xform T;
-        uint32_t sphereId;
-        sphereCR(sc, h.sid, ray.time, c, r, T, sphereId);
-        V3 n = normalize(rayAt(ray, h.a) - c);
-        backside = dot(n, -ray.direction) < 0.0f;
-        material = sc.spheres[sphereId].material;
-    }
-}
-
 // Closest-hit tracing of a stream of rays.  Every wave owns a contiguous run of
 // items and keeps its 64 lanes busy: a lane whose ray has finished writes its
 // result and takes the wave's next item, so lanes do not wait for the longest ray
 // of a fixed group of 64.  The hand-out is a ballot and a popcount inside the wave;
-// no memory atomics.
-//   KIND 0: items are path slots (rays of live paths; result = hit record)
-//   KIND 1: items are queued shadow rays (result = contribution added if the chosen light is hit)
+// no memory atomics.  One launch covers both kinds of item:
+//   waves [0, slotWaves)   items are path slots (rays of live paths; result = hit record)
+//   waves [slotWaves, ..)  items are queued shadow rays (result = contribution added if
+//                          the chosen light is hit)
+// Within a lane the walk alternates two phases: node steps, repeated while at least
+// kWalkLanes lanes of the wave are walking, and then the surface tests that became due
+// (a leaf whose box was hit), done together.  The order of tests seen by one ray is
+// unchanged.
 #ifndef PT_ITEMS_PER_LANE
 #define PT_ITEMS_PER_LANE 4
 #endif
@@ -179,9 +167,9 @@ constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
-template <int KIND, bool DYN, bool LDS>
+template <bool DYN, bool LDS>
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters, int parity,
-                                                   float* __restrict__ samples, uint32_t shadowCap)
+                                                   float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
 {
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
     // per-lane gathers of the walk off the vector memory path
@@ -198,16 +186,18 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
         nodes = ldsGeo;
         surf = ldsGeo + nNode4;
     }
-    const uint32_t waveIdx = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
-    uint32_t pos = waveIdx * (64u * kItemsPerLane);
-    uint32_t endPos = pos + 64u * kItemsPerLane;
-    uint32_t itemBase = 0; // KIND 1: first entry of the wave's shard queue
-    if (KIND == 0) {
-        endPos = min(endPos, pool.nSlots);
+    const bool shadow = waveIdx >= slotWaves; // the same for every lane of the wave
+    uint32_t pos, endPos;
+    uint32_t itemBase = 0; // shadow waves: first entry of the wave's shard queue
+    if (!shadow) {
+        pos = waveIdx * (64u * kItemsPerLane);
+        endPos = min(pos + 64u * kItemsPerLane, pool.nSlots);
     } else {
         // the wave's run lies inside one shard queue (shadowCap is a multiple of the run length)
+        pos = (waveIdx - slotWaves) * (64u * kItemsPerLane);
         const uint32_t shard = pos / shadowCap;
         if (shard >= kShards)
             return;
@@ -226,10 +216,9 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
     uint32_t cur = 0;
     uint32_t pending = kInner; // leaf surface whose box was hit and whose test is due
     HitLite best = noHit();
-    // KIND 1: what the shadow ray carries
-    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // contribution, bits light | destination-is-sample
-    float4 lightLe = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // emission of the light's front side, bits fast-path flag
-    V3 destValue = v3(0.0f);                              // current value of the accumulator the result is added to
+    // shadow rays: what to add on arrival, where, and the current value there
+    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    V3 destValue = v3(0.0f);
     uint32_t dest = 0, destW = 0;
 
     for (;;) {
@@ -241,7 +230,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
             const uint32_t cand = pos + uint32_t(__popcll(idle & below));
             if (!have && cand < endPos) {
                 item = cand;
-                if (KIND == 0) {
+                if (!shadow) {
                     const float4 d_s = pool.d_s[item];
                     if (((fbits(d_s.w) >> 16) & 3u) == kActive) {
                         const float4 o_t = pool.o_t[item];
@@ -251,9 +240,8 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
                 } else {
                     const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
                     payload = pool.sh_c[itemBase + item];
-                    lightLe = pool.sh_l[itemBase + item];
                     dest = fbits(sd.w);
-                    if (fbits(payload.w) & 0x80000000u) {
+                    if (fbits(payload.w) & kDestIsSample) {
                         const float* p = samples + 3 * size_t(dest);
                         destValue = v3(p[0], p[1], p[2]);
                     } else {
@@ -290,33 +278,46 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
                 amax = best.a;
             pending = kInner;
         }
-        if (have) {
-            if (cur >= sc.n_nodes) {
-                have = false;
-                if (KIND == 0) {
-                    pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
-                                                fbits(best.a), fbits(best.u), fbits(best.v));
-                } else {
-                    const uint32_t lightSurf = fbits(payload.w) & 0x7FFFFFFFu;
-                    if (best.sid != PT_NO_HIT && best.sid == lightSurf) {
-                        V3 le;
-                        if (fbits(lightLe.w) & 1u) {
-                            le = best.backside ? v3(0.0f) : v3(lightLe.x, lightLe.y, lightLe.z);
-                        } else {
-                            int lmat;
-                            bool lback;
-                            hitMaterial(sc, ray, best, lmat, lback);
-                            le = materialLe(sc, lmat, lback);
-                        }
-                        V3 sum = destValue + v3(payload.x, payload.y, payload.z) * le;
-                        if (fbits(payload.w) & 0x80000000u) {
-                            float* p = samples + 3 * size_t(dest);
-                            p[0] = sum.x;
-                            p[1] = sum.y;
-                            p[2] = sum.z;
-                        } else {
-                            pool.rad_p[dest] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(destW));
-                        }
+        if (have && cur >= sc.n_nodes) {
+            have = false;
+            if (!shadow) {
+                pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
+                                            fbits(best.a), fbits(best.u), fbits(best.v));
+            } else if (best.sid != PT_NO_HIT && best.sid == (fbits(payload.w) & kLightMask)) {
+                // the chosen light is what the ray sees (reference src/15/pathtracer.cpp:102-107);
+                // which side: triangles know from the hit test, spheres from the hit point
+                // (reference src/15/surface_sphere.hpp:29-34)
+                bool back = best.backside;
+                const float4 l0 = surf[3 * best.sid + 0];
+                if (fbits(l0.w) > kTriDynamic) {
+                    V3 c = v3(l0.x, l0.y, l0.z);
+                    if (DYN && fbits(l0.w) == kSphDynamic) {
+                        float r;
+                        Xform T;
+                        uint32_t sphereId;
+                        sphereCR(sc, best.sid, ray.time, c, r, T, sphereId);
+                    }
+                    V3 n = normalize(rayAt(ray, best.a) - c);
+                    back = dot(n, -ray.direction) < 0.0f;
+                }
+                V3 add = v3(payload.x, payload.y, payload.z);
+                bool doAdd = true;
+                if (back) {
+                    doAdd = (fbits(payload.w) & kBackEmits) != 0;
+                    if (doAdd) {
+                        const float4 pb = pool.sh_b[itemBase + item];
+                        add = v3(pb.x, pb.y, pb.z);
+                    }
+                }
+                if (doAdd) {
+                    V3 sum = destValue + add;
+                    if (fbits(payload.w) & kDestIsSample) {
+                        float* p = samples + 3 * size_t(dest);
+                        p[0] = sum.x;
+                        p[1] = sum.y;
+                        p[2] = sum.z;
+                    } else {
+                        pool.rad_p[dest] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(destW));
                     }
                 }
             }
@@ -324,7 +325,10 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
     }
 }
 
-__global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathParams pp, uint32_t* __restrict__ counters,
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, Pool pool, PathParams pp, uint32_t* __restrict__ counters,
                                                    int parity, float* __restrict__ samples, uint32_t shadowCap)
 {
     __shared__ uint32_t lds[5];
@@ -337,9 +341,9 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
     }
     bool finished = false;
     bool haveShadow = false;
-    V3 shOrigin, shDir, shC, shLe = v3(0.0f);
+    V3 shOrigin, shDir, shC, shBack = v3(0.0f);
     float shTime = 0.0f;
-    uint32_t shLight = 0, shFast = 0;
+    uint32_t shLight = 0;
     V3 radiance = v3(0.0f);
     uint32_t pathLocal = 0;
 
@@ -400,15 +404,19 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
                             shLight = lightSurf;
                             haveShadow = true;
                             // emission of the chosen light, looked up here so that the tracing
-                            // kernel needs no table reads when the shadow ray arrives
-                            const float4 l0 = sc.surf[3 * size_t(lightSurf) + 0];
-                            if (fbits(l0.w) <= kTriDynamic) {
-                                const float4 l1 = sc.surf[3 * size_t(lightSurf) + 1];
-                                const int lmat = sc.meshes[fbits(l1.w)].material;
-                                shLe = materialLe(sc, lmat, false);
-                                const V3 back = materialLe(sc, lmat, true);
-                                shFast = (back.x == 0.0f && back.y == 0.0f && back.z == 0.0f) ? 1u : 0u;
-                            }
+                            // kernel needs no material tables when the shadow ray arrives: the
+                            // ray carries contribution * emission for the light's front and,
+                            // if that side emits too, for its back
+                            int lmat;
+                            if (fbits(sc.surf[3 * size_t(lightSurf) + 0].w) <= kTriDynamic)
+                                lmat = int(sc.surfAttr[lightSurf].w & 0xFFFFFFu);
+                            else
+                                lmat = sc.spheres[sc.surfAttr[lightSurf].x].material;
+                            // (a black back side still matters if the product is NaN: NaN != 0)
+                            shBack = shC * materialLe(sc, lmat, true);
+                            if (shBack.x != 0.0f || shBack.y != 0.0f || shBack.z != 0.0f)
+                                shLight |= kBackEmits;
+                            shC = shC * materialLe(sc, lmat, false);
                         }
                     }
                 }
@@ -453,8 +461,9 @@ __global__ void __launch_bounds__(256) shadeKernel(DevScene sc, Pool pool, PathP
         const uint32_t e = shard * shadowCap + pos;
         pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
         pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : slot));
-        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? 0x80000000u : 0u)));
-        pool.sh_l[e] = make_float4(shLe.x, shLe.y, shLe.z, __uint_as_float(shFast));
+        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? kDestIsSample : 0u)));
+        if (shLight & kBackEmits)
+            pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
     }
 }
 
@@ -528,7 +537,7 @@ Pool carvePool(void* base, uint32_t n)
     p.sh_o = static_cast<float4*>(take(q * 16));
     p.sh_d = static_cast<float4*>(take(q * 16));
     p.sh_c = static_cast<float4*>(take(q * 16));
-    p.sh_l = static_cast<float4*>(take(q * 16));
+    p.sh_b = static_cast<float4*>(take(q * 16));
     p.key = static_cast<uint2*>(take(size_t(n) * 8));
     p.nSlots = n;
     p.nShards = std::min<uint32_t>(kShards, n / 256u);
@@ -581,14 +590,14 @@ void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Po
     const dim3 gridSlots(pool.nSlots / 256u);
     const uint32_t run = 64u * kItemsPerLane;
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
-    const dim3 gridTrace(((pool.nSlots + run - 1) / run + 3u) / 4u);
-    const dim3 gridShadow((shadowCap * kShards / run + 3u) / 4u);
+    // tracing: whole blocks of slot waves, then whole blocks of shadow-queue waves
+    const uint32_t slotWaves = ((pool.nSlots + run - 1) / run + 3u) / 4u * 4u;
+    const uint32_t shadowWaves = (shadowCap * kShards / run + 3u) / 4u * 4u;
+    const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
     const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
     hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
-    hipLaunchKernelGGL((traceKernel<0, DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
-                       w.samples, shadowCap);
-    hipLaunchKernelGGL((traceKernel<1, DYN, LDS>), gridShadow, block, lds, stream, sc->dev, pool, w.counters, parity,
-                       w.samples, shadowCap);
+    hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
+                       w.samples, shadowCap, slotWaves);
     hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples,
                        shadowCap);
 }
@@ -646,7 +655,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     perBatch = std::min<uint64_t>(perBatch, nsTotal);
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    uint64_t wantSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 21);
+    uint64_t wantSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 22);
     wantSlots = std::min<uint64_t>(wantSlots, (idsPerSample * perBatch + 255) / 256 * 256);
     wantSlots = std::max<uint64_t>(wantSlots, 256);
     int rc = ensureBuffers(sc, uint32_t(wantSlots), npix * perBatch, npix);
