@@ -134,22 +134,31 @@ def main():
     out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     # every rank renders its own batch of samples of the same frame (its own seed)
-    params = pt.make_params(W, H, sqrt_spp, seed=42 + rank, flags=abi.PT_RENDER_SUM_ONLY if world > 1 else 0)
+    params = pt.make_params(W, H, sqrt_spp, seed=42)
 
+    from path_tracing_amd import distributed as shard
     events = []
+
+    def render(p, buf):
+        dev.render_device(cam, p, buf.data_ptr(), stream.cuda_stream)
 
     def step(timed=False):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        dev.render_device(cam, params, out.data_ptr(), stream.cuda_stream)
+        if world == 1:
+            render(params, out)
+        else:
+            # the render of this rank's batch, then the exchange: one RCCL sum-reduce to rank 0
+            for p in shard.shard_params(params, "batches", world, rank):
+                render(p, out)
         if timed:
             e1.record(stream)
             events.append((e0, e1))
         if world > 1:
             dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
-                out.mul_(1.0 / (spp * world))
+                out.div_(float(spp * world))
 
     def barrier():
         if world > 1:

@@ -95,6 +95,11 @@ PT_HD void sincosf(float xf, float& s, float& c)
         s = c = float(x - x);
         return;
     }
+    if (x == 0.0) { // keeps the sign of a zero argument, as the C library does
+        s = xf;
+        c = 1.0f;
+        return;
+    }
     double r;
     int q = reducePio2(x, r);
     double sr = sinKernel(r);

@@ -1,0 +1,89 @@
+"""Sharding over ranks: the plans, and a two-process gloo run of every mode with the CPU oracle as renderer."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import path_tracing_amd as pt
+from path_tracing_amd import distributed as shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tile_plan_partitions_the_image():
+    for world in (1, 2, 3, 8):
+        cover = np.zeros((70, 100), np.int32)
+        for rank in range(world):
+            for (x0, y0, x1, y1) in shard.plan_tiles(100, 70, world, rank, tile=32):
+                cover[y0:y1, x0:x1] += 1
+        assert np.all(cover == 1)
+
+
+def test_sample_and_frame_plans_partition():
+    for world in (1, 2, 3, 8):
+        for n in (1, 7, 16, 1024):
+            ranges = [shard.plan_samples(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            assert max(e - b for b, e in ranges) - min(e - b for b, e in ranges) <= 1
+        frames = sorted(sum((shard.plan_frames(240, world, r) for r in range(world)), []))
+        assert frames == list(range(240))
+
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import path_tracing_amd as pt
+from path_tracing_amd import distributed as shard
+import refbind
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+golden = os.path.join(%(root)r, "tests", "golden")
+scene = pt.LoadedScene(os.path.join(golden, "cornell.ptscene"))
+cam = pt.load_camera(os.path.join(golden, "cornell_square.ptcam"))
+O = refbind.Oracle()
+base = pt.make_params(40, 24, 3, seed=11)
+
+def render(p, out):
+    img = out.numpy()
+    part = O.render(scene.ptr, cam, p, math_mode=1, threads=2)
+    x0, y0, x1, y1 = p.tile_x0, p.tile_y0, p.tile_x1, p.tile_y1
+    if (x0, y0, x1, y1) == (0, 0, 0, 0):
+        x1, y1 = p.width, p.height
+    img[y0:y1, x0:x1] = part[y0:y1, x0:x1]
+
+for mode in ("tiles", "samples", "batches"):
+    out = torch.zeros((24, 40, 3), dtype=torch.float32)
+    shard.render_sharded(render, base, mode, out, world, rank,
+                         reduce_to_root=lambda t: dist.reduce(t, dst=0, op=dist.ReduceOp.SUM),
+                         scale_root=lambda t, d: t.div_(d))
+    if rank == 0:
+        np.save(os.path.join(%(out)r, mode + ".npy"), out.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_gloo_all_modes(tmp_path, oracle, golden_dir):
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                   check=True, env=env, timeout=300)
+    scene = pt.LoadedScene(os.path.join(golden_dir, "cornell.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "cornell_square.ptcam"))
+    base = pt.make_params(40, 24, 3, seed=11)
+    single = oracle.render(scene.ptr, cam, base, math_mode=1)
+    tiles = np.load(tmp_path / "tiles.npy")
+    assert tiles.tobytes() == single.tobytes()           # pixel sharding is result-invariant, bit for bit
+    samples = np.load(tmp_path / "samples.npy")
+    np.testing.assert_allclose(samples, single, rtol=2e-6, atol=1e-7)   # same samples, other addition order
+    batches = np.load(tmp_path / "batches.npy")
+    other = oracle.render(scene.ptr, cam, pt.make_params(40, 24, 3, seed=12), math_mode=1)
+    np.testing.assert_allclose(batches, (single + other) / 2, rtol=2e-6, atol=1e-7)
