@@ -61,6 +61,22 @@ def algorithmic_per_sample(cnt, n_lights):
     return bytes_, flops
 
 
+def measured_traffic(workload_name, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/collect_traffic.sh writes
+    profiles/traffic_<workload>.json from two rocprofv3 --pmc runs of this benchmark: FETCH_SIZE and
+    WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled as gfx950 needs for 16-byte-per-lane
+    streaming reads).  None when no such file is present."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload_name)
+    if not os.path.exists(path):
+        return None, "no PMC pass committed for this workload"
+    with open(path) as f:
+        t = json.load(f)
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None, "PMC file has no row for " + kernel
+    return k["hbm_bytes_per_launch"], t.get("how", "")
+
+
 def cpu_baseline(scene, cam, width, height, seed):
     """Time the compiled reference on the host cores on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -168,13 +184,18 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if rank == 0:
+        dev.profile(True)   # events between the kernels, on the launch stream, for the timed steps
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
-    # average duration of the render kernel: HIP events on the launch stream around each launch
+    # duration of the whole launch sequence of one render: HIP events on the launch stream
     last_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / len(events)
+    kernel_times = dev.kernel_times() if rank == 0 else {}
+    dev.profile(False)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -191,9 +212,25 @@ def main():
         cnt = cnt.as_dict()
         bytes_ps, flops_ps = algorithmic_per_sample(cnt, 0)
         launch_samples = float(W) * H * spp
-        kern_s = last_ms * 1e-3
-        ach_gbs = bytes_ps * launch_samples / kern_s / 1e9
-        ach_tf = flops_ps * launch_samples / kern_s / 1e12
+        n_s = max(cnt["path_samples"], 1)
+        # the reference algorithm's bytes, split by the kernel that does that part of the work
+        kernel_bytes_ps = {
+            "traceKernel": (cnt["node_visits"] * 32 + cnt["leaf_tests"] * 48) / n_s,
+            "shadeKernel": cnt["light_tests"] * 48 / n_s + 12,
+        }
+        kernels = {}
+        for name, (launches, total_ms) in kernel_times.items():
+            if launches:
+                kernels[name] = {"launches_per_step": launches / args.steps, "avg_us": total_ms / launches * 1e3,
+                                 "ms_per_step": total_ms / args.steps}
+        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        dk = kernels[dominant]
+        # one launch of the dominant kernel advances (samples of a render / its launches per render) samples
+        samples_per_launch = launch_samples / dk["launches_per_step"]
+        ach_gbs = kernel_bytes_ps.get(dominant, bytes_ps) * samples_per_launch / (dk["avg_us"] * 1e-6) / 1e9
+        # vector flops are priced over the whole launch sequence (they are spread over all kernels)
+        ach_tf = flops_ps * launch_samples / (last_ms * 1e-3) / 1e12
+        traffic, traffic_note = measured_traffic(args.workload, dominant)
         result = {
             "metric": "path samples/sec at 1080p", "value": value, "unit": "path samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,14 +240,20 @@ def main():
                        "sharding": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "renderPixelsKernel", "kernel_ms": last_ms,
-                         "algorithmic_bytes_per_sample": bytes_ps,
-                         "note": "algorithmic bytes = 32 B/node visit + 48 B/primitive test + 12 B/sample of the "
-                                 "reference algorithm; a fraction above 1 means the working set is served from "
-                                 "cache, i.e. the kernel is bound by vector ALU work, see roofline_valu"},
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": dominant, "kernel_avg_us": dk["avg_us"],
+                         "kernel_launches_per_step": dk["launches_per_step"],
+                         "samples_per_launch": samples_per_launch,
+                         "algorithmic_bytes_per_sample": kernel_bytes_ps.get(dominant, bytes_ps),
+                         "traffic_note": traffic_note,
+                         "note": "algorithmic bytes = 32 B per node visit + 48 B per primitive test of the reference "
+                                 "algorithm for the rays this kernel traces (work counts measured on this scene); a "
+                                 "scene whose tables fit LDS or cache is bound by vector ALU issue instead, see "
+                                 "roofline_valu"},
             "roofline_valu": {"bound": "fp32-valu", "achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach_tf / VALU_PEAK_TFLOPS, "algorithmic_flops_per_sample": flops_ps},
+                              "frac": ach_tf / VALU_PEAK_TFLOPS, "algorithmic_flops_per_sample": flops_ps,
+                              "over": "all kernels of one render (%.1f ms)" % last_ms},
+            "kernels": kernels,
             "work_per_sample": {k: cnt[k] / max(cnt["path_samples"], 1) for k in cnt if k != "path_samples"},
         }
         if not args.no_cpu_baseline and world == 1:

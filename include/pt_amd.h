@@ -294,6 +294,23 @@ int pt_render_counted(pt_scene* scene, const pt_camera* camera, const pt_render_
  * this scene (HIP events on the launch stream); negative if none yet. */
 float pt_last_kernel_ms(pt_scene* scene);
 
+/* Device time per kernel of the wavefront renderer (generate, trace, shade,
+ * resolve), measured with HIP events recorded on the launch stream between the
+ * kernels.  The reference has no counterpart (it has one loop and no kernels);
+ * this is what a benchmark prices against the hardware's limits.
+ * pt_scene_profile(scene, 1) clears the sums and switches the events on for the
+ * following pt_render* calls, (scene, 0) switches them off.  pt_scene_kernel_times
+ * waits for the scene's outstanding work, then writes up to `capacity` records
+ * and the number of kernels to *count. */
+typedef struct pt_kernel_time {
+    char name[24];
+    uint64_t launches;
+    double total_ms;
+} pt_kernel_time;
+
+int pt_scene_profile(pt_scene* scene, int enable);
+int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, int* count);
+
 /* ------------------------------------------------------- host-side helpers -- */
 
 /* Build the acceleration structure over [t0, t1] exactly as

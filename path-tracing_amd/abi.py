@@ -106,8 +106,12 @@ class pt_counters(C.Structure):
 
 
 # struct sizes as the C compiler lays them out (checked by tests against the library)
+class pt_kernel_time(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
 EXPECTED_SIZES = {
     "pt_transform": 40, "pt_animation": 88, "pt_texture": 48, "pt_material": 48, "pt_mesh": 40,
     "pt_sphere": 24, "pt_surface": 16, "pt_bvh_node": 32, "pt_envmap": 32, "pt_scene_desc": 240,
-    "pt_camera": 116, "pt_render_params": 64, "pt_hit": 16, "pt_counters": 56,
+    "pt_camera": 116, "pt_render_params": 64, "pt_hit": 16, "pt_counters": 56, "pt_kernel_time": 40,
 }

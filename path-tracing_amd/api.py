@@ -44,6 +44,8 @@ def lib():
         L.pt_version.restype = C.c_char_p
         L.pt_last_kernel_ms.restype = C.c_float
         L.pt_last_kernel_ms.argtypes = [C.c_void_p]
+        L.pt_scene_profile.argtypes = [C.c_void_p, C.c_int]
+        L.pt_scene_kernel_times.argtypes = [C.c_void_p, C.POINTER(abi.pt_kernel_time), C.c_int, C.POINTER(C.c_int)]
         L.pt_scene_destroy.argtypes = [C.c_void_p]
         L.pt_scene_destroy.restype = None
         L.pt_scene_desc_free.argtypes = [C.c_void_p]
@@ -512,6 +514,17 @@ class DeviceScene:
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.handle))
+
+    def profile(self, enable=True):
+        """Switch the per-kernel event timing on (clearing the sums) or off."""
+        _check(lib().pt_scene_profile(self.handle, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{kernel name: (launches, total milliseconds)} since profile(True)."""
+        recs = (abi.pt_kernel_time * 8)()
+        n = C.c_int(0)
+        _check(lib().pt_scene_kernel_times(self.handle, recs, 8, C.byref(n)))
+        return {recs[i].name.decode(): (int(recs[i].launches), float(recs[i].total_ms)) for i in range(min(n.value, 8))}
 
     def render_samples(self, cam, params):
         out = np.empty((n_samples(params), 3), np.float32)

@@ -568,6 +568,38 @@ float pt_last_kernel_ms(pt_scene* scene)
     return ms;
 }
 
+int pt_scene_profile(pt_scene* scene, int enable)
+{
+    if (!scene)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_profile: null scene");
+    DeviceGuard g(scene->device);
+    HIP_TRY(hipDeviceSynchronize());
+    scene->kt.collect();
+    if (enable)
+        scene->kt.reset();
+    scene->kt.enabled = enable != 0;
+    return PT_OK;
+}
+
+int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, int* count)
+{
+    if (!scene || !count || (capacity > 0 && !out))
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_kernel_times: null argument");
+    DeviceGuard g(scene->device);
+    HIP_TRY(hipDeviceSynchronize());
+    scene->kt.collect();
+    static const char* const names[KernelTimes::kKinds] = { "generateKernel", "traceKernel", "shadeKernel",
+                                                            "resolveKernel" };
+    *count = KernelTimes::kKinds;
+    for (int k = 0; k < KernelTimes::kKinds && k < capacity; k++) {
+        std::memset(&out[k], 0, sizeof(out[k]));
+        std::strncpy(out[k].name, names[k], sizeof(out[k].name) - 1);
+        out[k].launches = scene->kt.launches[k];
+        out[k].total_ms = scene->kt.ms[k];
+    }
+    return PT_OK;
+}
+
 int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                       float* out_rgb_per_sample)
 {

@@ -60,14 +60,83 @@ int upload(const T* host, size_t count, T** dev, std::vector<void*>& owned)
 
 // Work areas of the wavefront renderer, allocated on first use and kept.
 struct WavefrontBuffers {
-    void* pool = nullptr;       // path-state arrays, nSlots each
-    uint32_t nSlots = 0;
+    void* pool = nullptr;       // path-state arrays of the lanes
+    size_t poolCapacity = 0;    // bytes
     float* samples = nullptr;   // per-sample radiance of one batch
     uint64_t sampleCapacity = 0; // in samples (3 floats each)
     float* accum = nullptr;     // running per-pixel sums across batches
     uint64_t accumCapacity = 0; // in pixels
-    uint32_t* counters = nullptr;
+    uint32_t* counters = nullptr;     // one block of counters per lane
     uint32_t* hostCounters = nullptr; // pinned
+    uint32_t nLanes = 0;
+    hipStream_t shadeStream = nullptr; // the shading kernels of the two lanes run here, the tracing kernels on the caller's stream
+    hipEvent_t traced[2] = {nullptr, nullptr}, shaded[2] = {nullptr, nullptr};
+};
+
+// Per-kernel device time of the wavefront renderer, measured with pairs of events on the
+// stream a kernel is launched on.  begin(k) / end() bracket one launch; collect() (once the
+// streams have been synchronised) adds the elapsed times to the sums.
+struct KernelTimes {
+    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kKinds };
+    bool enabled = false;
+    std::vector<hipEvent_t> events; // pairs: start, stop
+    std::vector<int> kinds;         // kind of pair i
+    size_t used = 0;                // events in use
+    double ms[kKinds] = {0, 0, 0, 0};
+    uint64_t launches[kKinds] = {0, 0, 0, 0};
+
+    void reset()
+    {
+        used = 0;
+        for (int k = 0; k < kKinds; k++) {
+            ms[k] = 0;
+            launches[k] = 0;
+        }
+    }
+    void record(hipStream_t stream)
+    {
+        if (used == events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess)
+                return;
+            events.push_back(e);
+        }
+        (void)hipEventRecord(events[used], stream);
+        used++;
+    }
+    void begin(int kind, hipStream_t stream)
+    {
+        if (!enabled)
+            return;
+        if (kinds.size() <= used / 2)
+            kinds.resize(used / 2 + 1);
+        kinds[used / 2] = kind;
+        record(stream);
+    }
+    void end(hipStream_t stream)
+    {
+        if (enabled)
+            record(stream);
+    }
+    void collect()
+    {
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, events[i], events[i + 1]) == hipSuccess) {
+                ms[kinds[i / 2]] += double(t);
+                launches[kinds[i / 2]]++;
+            }
+        }
+        used = 0;
+    }
+    void release()
+    {
+        for (hipEvent_t e : events)
+            (void)hipEventDestroy(e);
+        events.clear();
+        kinds.clear();
+        used = 0;
+    }
 };
 
 struct pt_scene {
@@ -80,6 +149,7 @@ struct pt_scene {
     bool timed = false;
     bool hasDynamic = false; // some surface or sphere has a time-dependent (two-key) pose
     WavefrontBuffers wf;
+    KernelTimes kt;
 };
 
 

@@ -4,19 +4,18 @@
 // One path = one (pixel, sample).  A fixed pool of path slots lives in HBM as
 // structure-of-arrays of 16-byte records; every iteration of the host loop runs
 //
-//   generateKernel  slots without a path draw the next path number from a global
-//                   counter (one atomic per wave), compute the camera ray and
-//                   reset the path state (reference src/15/pathtracer.cpp:202-215,
-//                   camera.hpp:34-55);
-//   traceKernel     one lane per live slot: closest hit of its ray (reference
-//                   src/15/bvh.hpp:183-213); then one lane per queued shadow ray:
-//                   closest hit, and if it is the chosen light, add the prepared
-//                   contribution (reference src/15/pathtracer.cpp:99-107);
-//   shadeKernel     one lane per live slot: environment on a miss, else hit
-//                   record, scatter, emission, light pdfs, light sample, MIS,
-//                   Russian roulette (reference src/15/pathtracer.cpp:60-126);
-//                   queues the shadow ray with a wave-wide ballot + prefix sum;
-//                   a finished path writes its radiance to the sample buffer.
+//   traceKernel     closest hit (reference src/15/bvh.hpp:183-213) of the ray of
+//                   every live slot, and of every queued shadow ray: if that one
+//                   reaches the chosen light, the prepared contribution is added
+//                   (reference src/15/pathtracer.cpp:99-107);
+//   shadeKernel     one lane per slot: environment on a miss, else hit record,
+//                   scatter, emission, light pdfs, light sample, MIS, Russian
+//                   roulette (reference src/15/pathtracer.cpp:60-126); queues the
+//                   shadow ray; a finished path writes its radiance to the sample
+//                   buffer and its slot at once starts the next path: it draws a
+//                   path number (one atomic per block), computes the camera ray and
+//                   resets the path state (reference src/15/pathtracer.cpp:202-215,
+//                   camera.hpp:34-55).
 //
 // Finished radiances go to a sample buffer indexed [sample][pixel]; resolveKernel
 // then adds each pixel's samples in sample order -- the same sequence of float
@@ -99,47 +98,34 @@ PT_DEV uint32_t blockReserve(uint32_t* counter, bool want, uint32_t* lds /* 5 wo
     return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
-__global__ void __launch_bounds__(256) generateKernel(Pool pool, RenderArgs a, Batch b, uint32_t* __restrict__ counters,
-                                                      int parity)
+// The same for two independent reservations at once (two barriers instead of four).
+PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bool wantB, uint32_t* lds /* 10 words */,
+                          uint32_t& posA, uint32_t& posB)
 {
-    __shared__ uint32_t lds[5];
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t shard = blockIdx.x % pool.nShards;
-    if (blockIdx.x < kShards && threadIdx.x == 0)
-        counters[(kCtrShadow + parity * kShards + blockIdx.x) * kCtrStride] = 0; // queues this iteration's shadeKernel fills
-    float4 d_s = pool.d_s[slot];
-    const bool need = ((fbits(d_s.w) >> 16) & 3u) == kNeed;
-    const uint32_t local = blockReserve(&counters[shard * kCtrStride], need, lds);
-    if (!need)
-        return;
-    // shard q owns the groups of 64 path numbers g with g % nShards == q
-    const uint32_t group = (local >> 6) * pool.nShards + shard, inTile = local & 63u;
-    if (group >= b.totalIds >> 6) {
-        d_s.w = __uint_as_float(kDone << 16);
-        pool.d_s[slot] = d_s;
-        const uint64_t m = __ballot(true);
-        if (int(laneId()) == __ffsll((long long)m) - 1)
-            atomicAdd(&counters[kCtrDone * kCtrStride], uint32_t(__popcll(m)));
-        return;
+    const uint64_t maskA = __builtin_amdgcn_ballot_w64(wantA), maskB = __builtin_amdgcn_ballot_w64(wantB);
+    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    if (lane == 0) {
+        lds[wave] = uint32_t(__popcll(maskA));
+        lds[5 + wave] = uint32_t(__popcll(maskB));
     }
-    // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
-    const uint32_t tile = group / b.nS, sLocal = group % b.nS;
-    const int lx = int((tile % b.tilesX) * 8u + (inTile & 7u));
-    const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
-    if (lx >= a.tw || ly >= a.th)
-        return; // padding of an edge tile: not a path; the slot draws again next iteration
-    const int x = a.x0 + lx, y = a.y0 + ly;
-    const int smp = int(b.sFirst + sLocal);
-    Rng<false> rng;
-    rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
-    rng.n = 0;
-    rng.cnt = nullptr;
-    Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
-    pool.o_t[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
-    pool.d_s[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
-    pool.thr_n[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
-    pool.rad_p[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sLocal * b.npix + uint32_t(ly * a.tw + lx)));
-    pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t totalA = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[4] = totalA ? atomicAdd(counterA, totalA) : 0u;
+    }
+    if (threadIdx.x == 64) {
+        const uint32_t totalB = lds[5] + lds[6] + lds[7] + lds[8];
+        lds[9] = totalB ? atomicAdd(counterB, totalB) : 0u;
+    }
+    __syncthreads();
+    uint32_t baseA = lds[4], baseB = lds[9];
+    for (uint32_t w = 0; w < wave; w++) {
+        baseA += lds[w];
+        baseB += lds[5 + w];
+    }
+    const uint64_t below = (1ull << lane) - 1ull;
+    posA = baseA + uint32_t(__popcll(maskA & below));
+    posB = baseB + uint32_t(__popcll(maskB & below));
 }
 
 // Closest-hit tracing of a stream of rays.  Every wave owns a contiguous run of
@@ -168,9 +154,13 @@ constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lane
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
 template <bool DYN, bool LDS>
-__global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters, int parity,
+__global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                    float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
 {
+    // the queues this iteration's shadeKernel fills were read by the previous launch of this
+    // kernel; this launch reads the other set
+    if (blockIdx.x == 0 && threadIdx.x < kShards)
+        counters[(kCtrShadow + parity * kShards + threadIdx.x) * kCtrStride] = 0;
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
     // per-lane gathers of the walk off the vector memory path
     extern __shared__ float4 ldsGeo[];
@@ -328,17 +318,22 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, const
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
-__global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, Pool pool, PathParams pp, uint32_t* __restrict__ counters,
-                                                   int parity, float* __restrict__ samples, uint32_t shadowCap)
+__global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, Pool pool, RenderArgs a, Batch b,
+                                                                   uint32_t* __restrict__ counters, int parity,
+                                                                   float* __restrict__ samples, uint32_t shadowCap)
 {
-    __shared__ uint32_t lds[5];
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    bool active = false;
-    float4 d_s;
-    if (slot < pool.nSlots) {
-        d_s = pool.d_s[slot];
-        active = ((fbits(d_s.w) >> 16) & 3u) == kActive;
-    }
+    __shared__ uint32_t lds[10];
+    const PathParams pp = a.pp;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x; // the grid covers the slots exactly
+    // the whole record of the slot, whatever its state: one round trip to memory
+    float4 d_s = pool.d_s[slot];
+    float4 o_t = pool.o_t[slot];
+    float4 thr_n = pool.thr_n[slot];
+    float4 rad_p = pool.rad_p[slot];
+    const uint4 hw = pool.hit[slot];
+    const uint2 kw = pool.key[slot];
+    const uint32_t state = (fbits(d_s.w) >> 16) & 3u;
+    const bool active = state == kActive;
     bool finished = false;
     bool haveShadow = false;
     V3 shOrigin, shDir, shC, shBack = v3(0.0f);
@@ -348,11 +343,6 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
     uint32_t pathLocal = 0;
 
     if (active) {
-        const float4 o_t = pool.o_t[slot];
-        const uint4 hw = pool.hit[slot];
-        const float4 thr_n = pool.thr_n[slot];
-        const float4 rad_p = pool.rad_p[slot];
-        const uint2 kw = pool.key[slot];
         const int segment = int(fbits(d_s.w) & 0xFFFFu);
         Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
         V3 throughput = v3(thr_n.x, thr_n.y, thr_n.z);
@@ -443,20 +433,22 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
             p[0] = radiance.x;
             p[1] = radiance.y;
             p[2] = radiance.z;
-            d_s.w = __uint_as_float(kNeed << 16);
-            pool.d_s[slot] = d_s;
         } else {
-            pool.o_t[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
-            pool.d_s[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z,
-                                         __uint_as_float((kActive << 16) | uint32_t(segment + 1)));
-            pool.thr_n[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.n));
-            pool.rad_p[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(pathLocal));
+            o_t = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
+            d_s = make_float4(ray.direction.x, ray.direction.y, ray.direction.z,
+                              __uint_as_float((kActive << 16) | uint32_t(segment + 1)));
+            thr_n = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.n));
+            rad_p = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(pathLocal));
         }
     }
 
-    // queue the shadow ray in the shard's queue: one atomic per block, lanes ranked by ballots
+    // two reservations with one atomic per block each, lanes ranked by ballots: a place in the
+    // shard's shadow-ray queue, and a path number for every slot that is free now
+    const bool want = state == kNeed || finished;
     const uint32_t shard = blockIdx.x % pool.nShards;
-    const uint32_t pos = blockReserve(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow, lds);
+    uint32_t pos, local;
+    blockReserve2(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
+                  &counters[shard * kCtrStride], want, lds, pos, local);
     if (haveShadow) {
         const uint32_t e = shard * shadowCap + pos;
         pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
@@ -465,6 +457,43 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
         if (shLight & kBackEmits)
             pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
     }
+
+    if (want) {
+        // shard q owns the groups of 64 path numbers g with g % nShards == q
+        const uint32_t group = (local >> 6) * pool.nShards + shard, inTile = local & 63u;
+        // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
+        const uint32_t tile = group / b.nS, sLocal = group % b.nS;
+        const int lx = int((tile % b.tilesX) * 8u + (inTile & 7u));
+        const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
+        if (group >= b.totalIds >> 6) {
+            // no paths left: the slot is out of work for the rest of the batch
+            d_s.w = __uint_as_float(kDone << 16);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(true);
+            if (int(laneId()) == __ffsll((long long)m) - 1)
+                atomicAdd(&counters[kCtrDone * kCtrStride], uint32_t(__popcll(m)));
+        } else if (lx >= a.tw || ly >= a.th) {
+            // padding of an edge tile: not a path; the slot draws again next iteration
+            d_s.w = __uint_as_float(kNeed << 16);
+        } else {
+            const int x = a.x0 + lx, y = a.y0 + ly;
+            const int smp = int(b.sFirst + sLocal);
+            Rng<false> rng;
+            rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
+            rng.n = 0;
+            rng.cnt = nullptr;
+            Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+            o_t = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
+            d_s = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
+            thr_n = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
+            rad_p = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sLocal * b.npix + uint32_t(ly * a.tw + lx)));
+            pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
+        }
+    }
+    // every lane stores its whole record (changed or not): whole cache lines per wave
+    pool.o_t[slot] = o_t;
+    pool.d_s[slot] = d_s;
+    pool.thr_n[slot] = thr_n;
+    pool.rad_p[slot] = rad_p;
 }
 
 // Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
@@ -544,16 +573,19 @@ Pool carvePool(void* base, uint32_t n)
     return p;
 }
 
-int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npix)
+constexpr uint32_t kMaxLanes = 2;
+
+int ensureBuffers(pt_scene* sc, uint32_t slotsPerLane, uint32_t nLanes, uint64_t nSamples, uint64_t npix)
 {
     WavefrontBuffers& w = sc->wf;
-    if (w.nSlots < nSlots) {
+    const size_t needPool = poolBytes(slotsPerLane) * nLanes;
+    if (w.poolCapacity < needPool) {
         if (w.pool)
             (void)hipFree(w.pool);
         w.pool = nullptr;
-        w.nSlots = 0;
-        HIP_TRY(hipMalloc(&w.pool, poolBytes(nSlots)));
-        w.nSlots = nSlots;
+        w.poolCapacity = 0;
+        HIP_TRY(hipMalloc(&w.pool, needPool));
+        w.poolCapacity = needPool;
     }
     if (w.sampleCapacity < nSamples) {
         if (w.samples)
@@ -572,22 +604,40 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
         w.accumCapacity = npix;
     }
     if (!w.counters)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), kCtrWords * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), kMaxLanes * kCtrWords * sizeof(uint32_t)));
     if (!w.hostCounters)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), kCtrWords * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), kMaxLanes * kCtrWords * sizeof(uint32_t)));
+    if (nLanes > 1 && !w.shadeStream) {
+        HIP_TRY(hipStreamCreateWithFlags(&w.shadeStream, hipStreamNonBlocking));
+        for (uint32_t l = 0; l < kMaxLanes; l++) {
+            HIP_TRY(hipEventCreateWithFlags(&w.traced[l], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&w.shaded[l], hipEventDisableTiming));
+        }
+    }
     return PT_OK;
 }
 
 // node + surface tables up to this size are traced from LDS
 constexpr size_t kLdsGeoLimit = 16 * 1024;
 
-// generate, trace (path rays), trace (shadow rays), shade: one iteration of the renderer
+// A lane: a pool of path slots working through its own share of a batch's samples.  Two lanes
+// run side by side so that the tracing kernel of one (bound by vector instruction issue)
+// overlaps the shading kernel of the other (bound by memory latency).
+struct Lane {
+    Pool pool;
+    Batch b;
+    uint32_t* counters;
+    uint32_t* hostCounters;
+    float* samples; // the lane's part of the sample buffer
+    bool done;
+};
+
+// the tracing kernel of one iteration of a lane
 template <bool DYN, bool LDS>
-void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream, int parity)
+void launchTrace(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t stream, int parity)
 {
-    WavefrontBuffers& w = sc->wf;
+    const Pool& pool = ln.pool;
     const dim3 block(256);
-    const dim3 gridSlots(pool.nSlots / 256u);
     const uint32_t run = 64u * kItemsPerLane;
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
     // tracing: whole blocks of slot waves, then whole blocks of shadow-queue waves
@@ -595,20 +645,39 @@ void launchIteration(pt_scene* sc, const RenderArgs& a, const Batch& b, const Po
     const uint32_t shadowWaves = (shadowCap * kShards / run + 3u) / 4u * 4u;
     const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
     const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
-    hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, pool, a, b, w.counters, parity);
-    hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
-                       w.samples, shadowCap, slotWaves);
-    hipLaunchKernelGGL(shadeKernel, gridSlots, block, 0, stream, sc->dev, pool, a.pp, w.counters, parity, w.samples,
-                       shadowCap);
+    sc->kt.begin(KernelTimes::kTrace, stream);
+    hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, ln.counters, parity,
+                       ln.samples, shadowCap, slotWaves);
+    sc->kt.end(stream);
 }
 
-// Run one batch of samples [sFirst, sFirst + nS) of every pixel of the tile into the sample buffer.
-int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream)
+void launchShade(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t stream, int parity)
+{
+    const Pool& pool = ln.pool;
+    sc->kt.begin(KernelTimes::kShade, stream);
+    hipLaunchKernelGGL(shadeKernel, dim3(pool.nSlots / 256u), dim3(256), 0, stream, sc->dev, pool, a, ln.b, ln.counters,
+                       parity, ln.samples, shadowCapOf(pool.nSlots));
+    sc->kt.end(stream);
+}
+
+// Run the lanes until every path of their shares has finished.  Per iteration and lane:
+// generate + trace on the caller's stream, shade on the shading stream, chained by events
+// (shade after its trace, the next trace after that shade); with one lane everything is on
+// the caller's stream.
+int runLanes(pt_scene* sc, const RenderArgs& a, Lane* lanes, uint32_t nLanes, hipStream_t stream)
 {
     WavefrontBuffers& w = sc->wf;
-    HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
-    const uint64_t maxIters = (uint64_t(b.totalIds) / pool.nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
+    const bool two = nLanes > 1;
+    hipStream_t sShade = two ? w.shadeStream : stream;
+    HIP_TRY(hipMemsetAsync(w.counters, 0, kMaxLanes * kCtrWords * sizeof(uint32_t), stream));
+    uint64_t maxIters = 0;
+    for (uint32_t l = 0; l < nLanes; l++) {
+        const Pool& pool = lanes[l].pool;
+        HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
+        maxIters = std::max<uint64_t>(maxIters, (uint64_t(lanes[l].b.totalIds) / pool.nSlots + 2)
+                                                        * uint64_t(a.pp.maxSegments + 2) + 64);
+        lanes[l].done = false;
+    }
     const int checkEvery = 16;
     const bool dyn = sc->hasDynamic;
     const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
@@ -616,25 +685,61 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool
     uint64_t iter = 0;
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
-            if (dyn && lds)
-                launchIteration<true, true>(sc, a, b, pool, stream, int(iter & 1));
-            else if (dyn)
-                launchIteration<true, false>(sc, a, b, pool, stream, int(iter & 1));
-            else if (lds)
-                launchIteration<false, true>(sc, a, b, pool, stream, int(iter & 1));
-            else
-                launchIteration<false, false>(sc, a, b, pool, stream, int(iter & 1));
+            const int parity = int(iter & 1);
+            for (uint32_t l = 0; l < nLanes; l++) {
+                const Lane& ln = lanes[l];
+                if (ln.done)
+                    continue;
+                if (two && iter > 0)
+                    HIP_TRY(hipStreamWaitEvent(stream, w.shaded[l], 0));
+                if (dyn && lds)
+                    launchTrace<true, true>(sc, a, ln, stream, parity);
+                else if (dyn)
+                    launchTrace<true, false>(sc, a, ln, stream, parity);
+                else if (lds)
+                    launchTrace<false, true>(sc, a, ln, stream, parity);
+                else
+                    launchTrace<false, false>(sc, a, ln, stream, parity);
+                if (two) {
+                    HIP_TRY(hipEventRecord(w.traced[l], stream));
+                    HIP_TRY(hipStreamWaitEvent(sShade, w.traced[l], 0));
+                }
+                launchShade(sc, a, ln, sShade, parity);
+                if (two)
+                    HIP_TRY(hipEventRecord(w.shaded[l], sShade));
+            }
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (w.hostCounters[kCtrDone * kCtrStride] >= pool.nSlots)
+        // the shading stream is the last to finish an iteration
+        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kMaxLanes * kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               sShade));
+        HIP_TRY(hipStreamSynchronize(sShade));
+        sc->kt.collect();
+        bool all = true;
+        for (uint32_t l = 0; l < nLanes; l++) {
+            if (lanes[l].hostCounters[kCtrDone * kCtrStride] >= lanes[l].pool.nSlots)
+                lanes[l].done = true;
+            all = all && lanes[l].done;
+        }
+        if (all)
             break;
         if (iter > maxIters)
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
-    // a slot runs out of work one iteration after its last path finished, so every queued
-    // shadow ray has been traced by now
+    // the last paths may have queued shadow rays in the very last shading launch: trace those
+    // (the host has waited for both streams, so the caller's stream can take over)
+    for (uint32_t l = 0; l < nLanes; l++) {
+        const int parity = int(iter & 1);
+        if (dyn && lds)
+            launchTrace<true, true>(sc, a, lanes[l], stream, parity);
+        else if (dyn)
+            launchTrace<true, false>(sc, a, lanes[l], stream, parity);
+        else if (lds)
+            launchTrace<false, true>(sc, a, lanes[l], stream, parity);
+        else
+            launchTrace<false, false>(sc, a, lanes[l], stream, parity);
+    }
+    HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 
@@ -655,28 +760,49 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     perBatch = std::min<uint64_t>(perBatch, nsTotal);
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    uint64_t wantSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 22);
-    wantSlots = std::min<uint64_t>(wantSlots, (idsPerSample * perBatch + 255) / 256 * 256);
-    wantSlots = std::max<uint64_t>(wantSlots, 256);
-    int rc = ensureBuffers(sc, uint32_t(wantSlots), npix * perBatch, npix);
+    // two lanes share the slots when a batch has at least two samples per pixel
+    const uint32_t nLanes = (perBatch >= 2 && envU64("PT_WAVEFRONT_LANES", 1) >= 2) ? 2u : 1u;
+    uint64_t laneSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 22) / nLanes;
+    laneSlots = std::min<uint64_t>(laneSlots, (idsPerSample * ((perBatch + nLanes - 1) / nLanes) + 255) / 256 * 256);
+    laneSlots = std::max<uint64_t>(laneSlots / 256 * 256, 256);
+    int rc = ensureBuffers(sc, uint32_t(laneSlots), nLanes, npix * perBatch, npix);
     if (rc != PT_OK)
         return rc;
-    Pool pool = carvePool(sc->wf.pool, uint32_t(wantSlots));
+    WavefrontBuffers& w = sc->wf;
     HIP_TRY(hipEventRecord(sc->evStart, stream));
     for (uint32_t s = 0; s < nsTotal; s += uint32_t(perBatch)) {
-        Batch b;
-        b.tilesX = tilesX;
-        b.tilesY = tilesY;
-        b.nS = std::min<uint32_t>(uint32_t(perBatch), nsTotal - s);
-        b.sFirst = uint32_t(a.s0) + s;
-        b.npix = uint32_t(npix);
-        b.totalIds = uint32_t(idsPerSample * b.nS);
-        rc = runBatch(sc, a, b, pool, stream);
+        const uint32_t nS = std::min<uint32_t>(uint32_t(perBatch), nsTotal - s);
+        Lane lanes[kMaxLanes];
+        uint32_t used = 0, sLane = 0;
+        for (uint32_t l = 0; l < nLanes; l++) {
+            const uint32_t share = (nS - sLane + (nLanes - l) - 1) / (nLanes - l);
+            if (share == 0)
+                continue;
+            Lane& ln = lanes[used];
+            ln.pool = carvePool(static_cast<char*>(w.pool) + poolBytes(uint32_t(laneSlots)) * used, uint32_t(laneSlots));
+            ln.b.tilesX = tilesX;
+            ln.b.tilesY = tilesY;
+            ln.b.nS = share;
+            ln.b.sFirst = uint32_t(a.s0) + s + sLane;
+            ln.b.npix = uint32_t(npix);
+            ln.b.totalIds = uint32_t(idsPerSample * share);
+            ln.counters = w.counters + size_t(used) * kCtrWords;
+            ln.hostCounters = w.hostCounters + size_t(used) * kCtrWords;
+            ln.samples = w.samples + 3 * npix * sLane;
+            ln.done = false;
+            sLane += share;
+            used++;
+        }
+        rc = runLanes(sc, a, lanes, used, stream);
         if (rc != PT_OK)
             return rc;
         if (d_out) {
-            hipLaunchKernelGGL(resolveKernel, dim3((b.npix + 255u) / 256u), dim3(256), 0, stream, sc->wf.samples,
-                               sc->wf.accum, d_out, a, b, s == 0 ? 1 : 0, s + b.nS >= nsTotal ? 1 : 0);
+            Batch b = lanes[0].b; // the whole batch: its samples lie one lane after the other
+            b.nS = nS;
+            sc->kt.begin(KernelTimes::kResolve, stream);
+            hipLaunchKernelGGL(resolveKernel, dim3((b.npix + 255u) / 256u), dim3(256), 0, stream, w.samples, w.accum,
+                               d_out, a, b, s == 0 ? 1 : 0, s + nS >= nsTotal ? 1 : 0);
+            sc->kt.end(stream);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -722,5 +848,14 @@ void ptWavefrontRelease(pt_scene* scene)
         (void)hipFree(w.counters);
     if (w.hostCounters)
         (void)hipHostFree(w.hostCounters);
+    if (w.shadeStream)
+        (void)hipStreamDestroy(w.shadeStream);
+    for (uint32_t l = 0; l < kMaxLanes; l++) {
+        if (w.traced[l])
+            (void)hipEventDestroy(w.traced[l]);
+        if (w.shaded[l])
+            (void)hipEventDestroy(w.shaded[l]);
+    }
     w = WavefrontBuffers();
+    scene->kt.release();
 }
