@@ -183,7 +183,7 @@ class FlatScene:
         self.envmap.tex[:] = [-1] * 6
         self.nodes = np.zeros(0, NODE_DTYPE)
         self.depth = 0
-        self._keep = None
+        self._keep = []
 
     # -- animations / textures / materials
     def add_animation(self, anim):
@@ -397,7 +397,8 @@ class FlatScene:
         d.n_bvh_nodes = len(keep["nodes"])
         d.bvh_nodes = keep["nodes"].ctypes.data_as(C.POINTER(abi.pt_bvh_node))
         d.envmap = self.envmap
-        self._keep = keep
+        # every descriptor handed out stays valid for the life of the scene object
+        self._keep.append(keep)
         return d
 
     def build_bvh(self, t0=0.0, t1=0.0):

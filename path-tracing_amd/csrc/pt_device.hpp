@@ -52,7 +52,7 @@ struct DevMesh {
 struct DevScene {
     const float4* nodes;
     const float4* surf;
-    const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24);
+    const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24 | material type << 28);
                              // spheres (sphere index, 0, 0, material | flags << 24).  flags: 1 normals,
                              // 2 texcoords, 4 tangents, 8 mesh has a pose
     const float4* matConst;  // per material 2 rows: (value of tex[0] if constant, bits mask), (value of tex[1]
@@ -652,7 +652,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     uint32_t kind = fbits(r0.w);
     if (kind <= kTriDynamic) {
         float4 r2 = sc.surf[3 * size_t(h.sid) + 2];
-        const uint32_t flags = attr.w >> 24;
+        const uint32_t flags = (attr.w >> 24) & 0xFu;
         const bool animated = (flags & 8u) != 0;
         Quat rot = Quat{ 0.0f, 0.0f, 0.0f, 1.0f };
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);

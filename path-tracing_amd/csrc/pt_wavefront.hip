@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -54,7 +55,7 @@ struct Pool {
                    //   surface | kBackEmits | kDestIsSample
     float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
     uint32_t nSlots;
-    uint32_t nShards; // min(8, number of 256-slot blocks): shard of a block = blockIdx % nShards
+    uint32_t nShards; // min(8, number of shading blocks): shard of a block = blockIdx % nShards
 };
 
 // geometry of one batch of paths
@@ -98,34 +99,93 @@ PT_DEV uint32_t blockReserve(uint32_t* counter, bool want, uint32_t* lds /* 5 wo
     return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
-// The same for two independent reservations at once (two barriers instead of four).
-PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bool wantB, uint32_t* lds /* 10 words */,
-                          uint32_t& posA, uint32_t& posB)
+// The same for two independent reservations at once (two barriers instead of four), for a
+// block of WAVES waves.
+template <uint32_t WAVES>
+PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bool wantB,
+                          uint32_t* lds /* 2 * (WAVES + 1) words */, uint32_t& posA, uint32_t& posB)
 {
     const uint64_t maskA = __builtin_amdgcn_ballot_w64(wantA), maskB = __builtin_amdgcn_ballot_w64(wantB);
     const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    uint32_t* ldsA = lds;
+    uint32_t* ldsB = lds + WAVES + 1;
     if (lane == 0) {
-        lds[wave] = uint32_t(__popcll(maskA));
-        lds[5 + wave] = uint32_t(__popcll(maskB));
+        ldsA[wave] = uint32_t(__popcll(maskA));
+        ldsB[wave] = uint32_t(__popcll(maskB));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t totalA = lds[0] + lds[1] + lds[2] + lds[3];
-        lds[4] = totalA ? atomicAdd(counterA, totalA) : 0u;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < WAVES; w++)
+            total += ldsA[w];
+        ldsA[WAVES] = total ? atomicAdd(counterA, total) : 0u;
     }
     if (threadIdx.x == 64) {
-        const uint32_t totalB = lds[5] + lds[6] + lds[7] + lds[8];
-        lds[9] = totalB ? atomicAdd(counterB, totalB) : 0u;
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < WAVES; w++)
+            total += ldsB[w];
+        ldsB[WAVES] = total ? atomicAdd(counterB, total) : 0u;
     }
     __syncthreads();
-    uint32_t baseA = lds[4], baseB = lds[9];
+    uint32_t baseA = ldsA[WAVES], baseB = ldsB[WAVES];
     for (uint32_t w = 0; w < wave; w++) {
-        baseA += lds[w];
-        baseB += lds[5 + w];
+        baseA += ldsA[w];
+        baseB += ldsB[w];
     }
     const uint64_t below = (1ull << lane) - 1ull;
     posA = baseA + uint32_t(__popcll(maskA & below));
     posB = baseB + uint32_t(__popcll(maskB & below));
+}
+
+// Order the slots of a block by what their lanes are going to do, so that the lanes of one
+// wave mostly take the same branches: returns, for this thread, the index (within the block's
+// window of slots) of the slot it handles.  A counting sort over kClasses classes with wave
+// ballots; stable within a class.
+constexpr uint32_t kClasses = 8;
+template <uint32_t WAVES>
+PT_DEV uint32_t blockSortByClass(uint32_t cls, uint32_t* counts /* WAVES * kClasses words */,
+                                 uint16_t* perm /* WAVES * 64 entries */)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t rank = 0;
+    // counts[c * WAVES + w]: lanes of class c in wave w
+    for (uint32_t c = 0; c < kClasses; c++) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(cls == c);
+        if (cls == c)
+            rank = uint32_t(__popcll(m & below));
+        if (lane == c)
+            counts[c * WAVES + wave] = uint32_t(__popcll(m));
+    }
+    __syncthreads();
+    // exclusive prefix sum over the table, by the first wave: each lane sums its own entries,
+    // a scan over the lanes gives where they start
+    if (wave == 0) {
+        constexpr uint32_t kEntries = kClasses * WAVES, kPerLane = (kEntries + 63u) / 64u;
+        uint32_t v[kPerLane], sum = 0;
+        for (uint32_t k = 0; k < kPerLane; k++) {
+            const uint32_t i = lane * kPerLane + k;
+            v[k] = i < kEntries ? counts[i] : 0u;
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = uint32_t(__shfl_up(int(incl), d));
+            if (lane >= d)
+                incl += up;
+        }
+        uint32_t run = incl - sum;
+        for (uint32_t k = 0; k < kPerLane; k++) {
+            const uint32_t i = lane * kPerLane + k;
+            if (i < kEntries)
+                counts[i] = run;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+    perm[counts[cls * WAVES + wave] + rank] = uint16_t(threadIdx.x);
+    __syncthreads();
+    return perm[threadIdx.x];
 }
 
 // Closest-hit tracing of a stream of rays.  Every wave owns a contiguous run of
@@ -315,16 +375,66 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     }
 }
 
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4
+// Debug build only (-DPT_SHADE_TIMING): wave cycles per section of the shading kernel, summed
+// into spare counter lines (word (9 + k / 4) * 32 + k % 4 ... see PT_T_FLUSH) in units of 256 cycles.
+#ifdef PT_SHADE_TIMING
+#define PT_T_DECL() uint64_t ptT_last = __builtin_amdgcn_s_memtime(); uint32_t ptT_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT_T(k)                                                                        \
+    do {                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();                            \
+        ptT_acc[k] += uint32_t(__builtin_amdgcn_readfirstlane(int(now_ - ptT_last))); \
+        ptT_last = now_;                                                               \
+    } while (0)
+#define PT_T_FLUSH()                                                                   \
+    do {                                                                               \
+        if (laneId() == 0)                                                             \
+            for (int k_ = 0; k_ < 12; k_++)                                            \
+                atomicAdd(&counters[(9 + k_ / 4) * kCtrStride + 8 + (k_ % 4) * 2], ptT_acc[k_] >> 8); \
+    } while (0)
+#else
+#define PT_T_DECL()
+#define PT_T(k)
+#define PT_T_FLUSH()
 #endif
-__global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, Pool pool, RenderArgs a, Batch b,
-                                                                   uint32_t* __restrict__ counters, int parity,
-                                                                   float* __restrict__ samples, uint32_t shadowCap)
+
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256
+#endif
+constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK; // threads per block of the shading kernel
+constexpr uint32_t kShadeWaves = kShadeBlock / 64u;
+
+__global__ void __launch_bounds__(PT_SHADE_BLOCK) shadeKernel(DevScene sc, Pool pool, RenderArgs a, Batch b,
+                                                              uint32_t* __restrict__ counters, int parity,
+                                                              float* __restrict__ samples, uint32_t shadowCap)
 {
-    __shared__ uint32_t lds[10];
+    __shared__ uint32_t lds[2 * (kShadeWaves + 1)];
+    __shared__ uint32_t sortCounts[kShadeWaves * kClasses];
+    __shared__ uint16_t sortPerm[kShadeBlock];
     const PathParams pp = a.pp;
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x; // the grid covers the slots exactly
+    PT_T_DECL();
+    // The block owns a window of kShadeBlock slots (the grid covers the slots exactly).  Which
+    // thread takes which slot of the window is decided by what the slot needs: a new path
+    // (free, or its ray left the scene), or the material of the surface that was hit.
+    uint32_t slot;
+    {
+        const uint32_t mine = blockIdx.x * kShadeBlock + threadIdx.x;
+        const uint32_t st = (fbits(pool.d_s[mine].w) >> 16) & 3u;
+        uint32_t cls = 0;
+        if (st == kDone) {
+            cls = kClasses - 1;
+        } else if (st == kActive) {
+            const uint32_t sid = pool.hit[mine].x;
+            if (sid != PT_NO_HIT)
+                cls = min(1u + (sc.surfAttr[sid & 0x7FFFFFFFu].w >> 28), kClasses - 2u);
+        }
+#ifdef PT_SHADE_SORT
+        slot = blockIdx.x * kShadeBlock + blockSortByClass<kShadeWaves>(cls, sortCounts, sortPerm);
+#else
+        slot = mine;
+#endif
+        PT_T(0);
+    }
     // the whole record of the slot, whatever its state: one round trip to memory
     float4 d_s = pool.d_s[slot];
     float4 o_t = pool.o_t[slot];
@@ -332,6 +442,7 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
     float4 rad_p = pool.rad_p[slot];
     const uint4 hw = pool.hit[slot];
     const uint2 kw = pool.key[slot];
+    PT_T(1);
     const uint32_t state = (fbits(d_s.w) >> 16) & 3u;
     const bool active = state == kActive;
     bool finished = false;
@@ -366,8 +477,10 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
             hl.u = __uint_as_float(hw.z);
             hl.v = __uint_as_float(hw.w);
             Hit hr = makeHit(sc, ray, hl);
+            PT_T(2);
             Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng);
             radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
+            PT_T(3);
             if (sr.type == ScatterNone) {
                 finished = true;
             } else {
@@ -375,12 +488,15 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
                 if (sr.type == ScatterRandom && sc.n_lights > 0) {
                     float lightsP = lightsPdf<false>(sc, hr.position, sr.direction, ray.time, nullptr);
                     nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
+                    PT_T(4);
                     uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
                     if (lightIndex >= sc.n_lights)
                         lightIndex = sc.n_lights - 1;
                     const uint32_t lightSurf = sc.lights[lightIndex];
                     V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
+                    PT_T(5);
                     float lightDirP = lightsPdf<false>(sc, hr.position, lightDir, ray.time, nullptr);
+                    PT_T(6);
                     if (lightDirP > 0.0f) {
                         Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
                         if (lightSR.p > 0.0f) {
@@ -410,6 +526,7 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
                         }
                     }
                 }
+                PT_T(7);
                 throughput = nextThroughput;
                 ray = makeRay(hr.position, sr.direction, ray.time);
                 float maxT = max_(throughput.x, max_(throughput.y, throughput.z));
@@ -442,12 +559,13 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
         }
     }
 
+    PT_T(8);
     // two reservations with one atomic per block each, lanes ranked by ballots: a place in the
     // shard's shadow-ray queue, and a path number for every slot that is free now
     const bool want = state == kNeed || finished;
     const uint32_t shard = blockIdx.x % pool.nShards;
     uint32_t pos, local;
-    blockReserve2(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
+    blockReserve2<kShadeWaves>(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
                   &counters[shard * kCtrStride], want, lds, pos, local);
     if (haveShadow) {
         const uint32_t e = shard * shadowCap + pos;
@@ -458,6 +576,7 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
             pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
     }
 
+    PT_T(9);
     if (want) {
         // shard q owns the groups of 64 path numbers g with g % nShards == q
         const uint32_t group = (local >> 6) * pool.nShards + shard, inTile = local & 63u;
@@ -489,11 +608,14 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeKernel(DevScene sc, 
             pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
         }
     }
+    PT_T(10);
     // every lane stores its whole record (changed or not): whole cache lines per wave
     pool.o_t[slot] = o_t;
     pool.d_s[slot] = d_s;
     pool.thr_n[slot] = thr_n;
     pool.rad_p[slot] = rad_p;
+    PT_T(11);
+    PT_T_FLUSH();
 }
 
 // Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
@@ -537,8 +659,8 @@ uint64_t envU64(const char* name, uint64_t dflt)
 // capacity of one shard's shadow queue: the slots of the blocks of that shard, rounded up to whole wave runs
 uint32_t shadowCapOf(uint32_t nSlots)
 {
-    const uint32_t blocks = nSlots / 256u;
-    const uint32_t perShard = (blocks + kShards - 1) / kShards * 256u;
+    const uint32_t blocks = nSlots / kShadeBlock;
+    const uint32_t perShard = (blocks + kShards - 1) / kShards * kShadeBlock;
     const uint32_t run = 64u * kItemsPerLane;
     return (perShard + run - 1) / run * run;
 }
@@ -569,7 +691,7 @@ Pool carvePool(void* base, uint32_t n)
     p.sh_b = static_cast<float4*>(take(q * 16));
     p.key = static_cast<uint2*>(take(size_t(n) * 8));
     p.nSlots = n;
-    p.nShards = std::min<uint32_t>(kShards, n / 256u);
+    p.nShards = std::min<uint32_t>(kShards, n / kShadeBlock);
     return p;
 }
 
@@ -655,7 +777,7 @@ void launchShade(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t 
 {
     const Pool& pool = ln.pool;
     sc->kt.begin(KernelTimes::kShade, stream);
-    hipLaunchKernelGGL(shadeKernel, dim3(pool.nSlots / 256u), dim3(256), 0, stream, sc->dev, pool, a, ln.b, ln.counters,
+    hipLaunchKernelGGL(shadeKernel, dim3(pool.nSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, sc->dev, pool, a, ln.b, ln.counters,
                        parity, ln.samples, shadowCapOf(pool.nSlots));
     sc->kt.end(stream);
 }
@@ -715,6 +837,19 @@ int runLanes(pt_scene* sc, const RenderArgs& a, Lane* lanes, uint32_t nLanes, hi
                                sShade));
         HIP_TRY(hipStreamSynchronize(sShade));
         sc->kt.collect();
+#ifdef PT_SHADE_TIMING
+        if (std::getenv("PT_SHADE_TIMING_PRINT")) {
+            static const char* names[12] = { "sort", "state", "makeHit", "scatter+Le", "lightsPdf1", "lightSample", "lightsPdf2",
+                                             "toDirection+emission", "rr+finish", "reserve", "generate", "stores" };
+            double tot = 0;
+            for (int k = 0; k < 12; k++)
+                tot += w.hostCounters[(9 + k / 4) * kCtrStride + 8 + (k % 4) * 2];
+            fprintf(stderr, "shade sections (%% of wave cycles, iter %llu):", (unsigned long long)iter);
+            for (int k = 0; k < 12; k++)
+                fprintf(stderr, " %s=%.1f", names[k], 100.0 * w.hostCounters[(9 + k / 4) * kCtrStride + 8 + (k % 4) * 2] / tot);
+            fprintf(stderr, "  total=%.3g cycles/wave-launch\n", tot * 256.0 / (double(iter) * (lanes[0].pool.nSlots / 64)));
+        }
+#endif
         bool all = true;
         for (uint32_t l = 0; l < nLanes; l++) {
             if (lanes[l].hostCounters[kCtrDone * kCtrStride] >= lanes[l].pool.nSlots)
@@ -763,8 +898,8 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     // two lanes share the slots when a batch has at least two samples per pixel
     const uint32_t nLanes = (perBatch >= 2 && envU64("PT_WAVEFRONT_LANES", 1) >= 2) ? 2u : 1u;
     uint64_t laneSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 22) / nLanes;
-    laneSlots = std::min<uint64_t>(laneSlots, (idsPerSample * ((perBatch + nLanes - 1) / nLanes) + 255) / 256 * 256);
-    laneSlots = std::max<uint64_t>(laneSlots / 256 * 256, 256);
+    laneSlots = std::min<uint64_t>(laneSlots, idsPerSample * ((perBatch + nLanes - 1) / nLanes));
+    laneSlots = std::max<uint64_t>((laneSlots + kShadeBlock - 1) / kShadeBlock * kShadeBlock, kShadeBlock); // whole shading blocks
     int rc = ensureBuffers(sc, uint32_t(laneSlots), nLanes, npix * perBatch, npix);
     if (rc != PT_OK)
         return rc;

@@ -115,6 +115,18 @@ def gen_family_vectors(R):
         rs.close()
 
 
+def gen_mesh_vectors(R):
+    """Primary hits and per-sample radiance of the seeded displaced-grid mesh (tests/scenes.py
+    big_mesh_scene(150): 45 002 triangles, tree too large for the on-chip copy of small scenes)."""
+    s, cam = scenes.big_mesh_scene(150)
+    d = s.desc()
+    rs = R.scene(C.byref(d))
+    assert rs.bvh_mismatch == 0
+    np.save(out("mesh150_hits_96x54.npy"), rs.primary_hits(cam, pt.make_params(96, 54, 1)))
+    np.save(out("mesh150_samples_32x18x4.npy"), rs.render_samples(cam, pt.make_params(32, 18, 2)))
+    rs.close()
+
+
 def gen_kat(R):
     rng = np.random.default_rng(7)
     n = 256
@@ -152,7 +164,7 @@ def main():
     args = ap.parse_args()
     R = refbind.Reference()
     steps = {"cornell": gen_cornell, "cornell_vectors": gen_cornell_vectors, "families": gen_family_vectors,
-             "kat": gen_kat}
+             "mesh": gen_mesh_vectors, "kat": gen_kat}
     for name, fn in steps.items():
         if args.only and args.only != name:
             continue

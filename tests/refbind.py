@@ -277,6 +277,24 @@ class Oracle:
                                                C.c_float(amin), C.c_float(amax), math_mode, out))
         return hits_to_numpy(out)
 
+    def trace_rays_ordered(self, desc, origins, directions, times=None, amin=1e-4, amax=np.finfo(np.float32).max,
+                           math_mode=1, stack_limit=128):
+        """CPU model of the device's near-child-first traversal; returns (hits, stats dict)."""
+        origins = np.ascontiguousarray(origins, np.float32)
+        directions = np.ascontiguousarray(directions, np.float32)
+        n = len(origins)
+        tp = None
+        if times is not None:
+            times = np.ascontiguousarray(times, np.float32)
+            tp = _f(times)
+        out = (abi.pt_hit * n)()
+        stats = (C.c_uint64 * 67)()
+        self._check(self.lib.oracle_trace_rays_ordered(desc, C.c_uint64(n), _f(origins), _f(directions), tp,
+                                                       C.c_float(amin), C.c_float(amax), math_mode,
+                                                       C.c_uint32(stack_limit), out, stats))
+        return hits_to_numpy(out), {"box_tests": int(stats[0]), "fell_back": int(stats[1]),
+                                    "deepest": int(stats[2]), "depth_hist": [int(x) for x in stats[3:67]]}
+
     def kat_warp(self, which, u0, u1, param=None, math_mode=0):
         u0 = np.ascontiguousarray(u0, np.float32)
         u1 = np.ascontiguousarray(u1, np.float32)

@@ -141,3 +141,77 @@ def test_converged_image_rmse(cornell, golden_dir):
     # two independent 4096-spp estimates of the same image: per-pixel noise ~ sigma * sqrt(2 / 4096)
     assert rmse < 0.02, rmse
     assert abs(float(img.mean()) - float(ref.mean())) < 2e-3
+
+
+def test_mesh_primary_hits_and_samples(golden_dir, oracle):
+    """A 45 002-triangle displaced grid: the tree no longer fits on chip, so the tracing kernel reads it
+    from memory.  Against the oracle bit for bit, and against vectors produced by the reference."""
+    s, cam = scenes.big_mesh_scene(150)
+    d = s.desc()
+    p_hits = pt.make_params(96, 54, 1)
+    p_smp = pt.make_params(32, 18, 2)
+    with pt.DeviceScene(s) as dev:
+        hits = dev.primary_hits(cam, p_hits)
+        smp = dev.render_samples(cam, p_smp)
+        img = dev.render(cam, pt.make_params(48, 27, 3))
+    assert hits.tobytes() == oracle.primary_hits(C.byref(d), cam, p_hits, math_mode=1).tobytes()
+    golden = np.load(os.path.join(golden_dir, "mesh150_hits_96x54.npy"))
+    # ids and sides as the reference has them; distances differ by an ulp where the camera's
+    # rotation went through a C-library sine or cosine
+    assert np.array_equal(hits["surface"], golden["surface"])
+    assert np.array_equal(hits["material"], golden["material"])
+    assert np.array_equal(hits["backside"], golden["backside"])
+    np.testing.assert_allclose(hits["a"], golden["a"], rtol=1e-5)
+    assert same_bits(smp, oracle.render_samples(C.byref(d), cam, p_smp, math_mode=1))
+    assert rel_outliers(smp, np.load(os.path.join(golden_dir, "mesh150_samples_32x18x4.npy"))) <= OUTLIER_FRACTION
+    want = oracle.render(C.byref(d), cam, pt.make_params(48, 27, 3), math_mode=1)
+    assert same_bits(img, want)
+
+
+def test_update_bvh_between_frames(oracle):
+    """Frame loop of the reference's animation program (src/07/pathtracer-frames.cpp:205-233): the scene
+    stays on the device, only the tree over the frame's shutter interval is replaced."""
+    s, cam, p = scenes.build("animated")
+    with pt.DeviceScene(s) as dev:
+        for (t0, t1) in [(p.t0, p.t1), (6.0, 6.4), (0.5, 0.5)]:
+            nodes = s.build_bvh(t0, t1)
+            dev.update_bvh(nodes)
+            q = pt.make_params(24, 14, 2, seed=5, t0=t0, t1=t1)
+            got = dev.render_samples(cam, q)
+            d = s.desc()
+            assert same_bits(got, oracle.render_samples(C.byref(d), cam, q, math_mode=1)), (t0, t1)
+
+
+def test_kernel_times_are_recorded(cornell):
+    scene, cam, dev = cornell
+    dev.profile(True)
+    dev.render(cam, pt.make_params(64, 64, 2))
+    times = dev.kernel_times()
+    dev.profile(False)
+    assert times["traceKernel"][0] > 0 and times["traceKernel"][1] > 0.0
+    assert times["shadeKernel"][0] > 0 and times["shadeKernel"][1] > 0.0
+    assert times["resolveKernel"][0] == 1
+
+
+def test_full_size_properties(oracle, golden_dir):
+    """The benchmark's image size (1920x1080), through properties that need no full-size oracle render:
+    primary hits against the oracle (2 M rays, seconds on the CPU), a tile of the full render bit for
+    bit, sample ranges adding up, and the image mean against the converged reference image."""
+    scene = pt.LoadedScene(os.path.join(golden_dir, "cornell_glossy.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "cornell_wide.ptcam"))
+    W, H = 1920, 1080
+    with pt.DeviceScene(scene) as dev:
+        p1 = pt.make_params(W, H, 1)
+        hits = dev.primary_hits(cam, p1)
+        assert hits.tobytes() == oracle.primary_hits(scene.ptr, cam, p1, math_mode=1).tobytes()
+        full = dev.render(cam, pt.make_params(W, H, 4))
+        assert np.isfinite(full).all()
+        tile = np.zeros_like(full)
+        dev.render(cam, pt.make_params(W, H, 4, tile=(901, 333, 1187, 700)), out=tile)
+        assert same_bits(tile[333:700, 901:1187], full[333:700, 901:1187])
+        a = dev.render(cam, pt.make_params(W, H, 4, samples=(0, 7), flags=pt.abi.PT_RENDER_SUM_ONLY))
+        b = dev.render(cam, pt.make_params(W, H, 4, samples=(7, 16), flags=pt.abi.PT_RENDER_SUM_ONLY))
+        np.testing.assert_allclose((a + b) / 16.0, full, rtol=2e-5, atol=1e-6)
+        # one 64x64 block of the full image against the oracle, bit for bit
+        blk = oracle.render(scene.ptr, cam, pt.make_params(W, H, 4, tile=(928, 508, 992, 572)), math_mode=1)
+        assert same_bits(full[508:572, 928:992], blk[508:572, 928:992])

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B of library builds on one GPU: prints M samples/s of the Cornell workload per variant.
-# usage: profiles/ab_variants.sh SQRT_SPP variant...   (variants live in path-tracing_amd/lib/variants)
+# A/B of library builds on one GPU: prints M samples/s and per-kernel microseconds of the Cornell workload per variant.
+# usage: tools/ab_variants.sh SQRT_SPP variant...   (variants live in path-tracing_amd/lib/variants)
 spp=$1; shift
 for v in default "$@"; do
   if [ "$v" = default ]; then unset PT_AMD_LIB; else export PT_AMD_LIB=$GRAFT_REPO_ROOT/path-tracing_amd/lib/variants/libptamd_$v.so; fi
   for rep in 1 2; do
-    r=$(timeout -k 10 300 python bench.py --steps 2 --warmup 1 --sqrt-spp $spp --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f M samples/s  %.2f ms/step' % (d['value']/1e6, d['ms_per_step']))")
+    r=$(timeout -k 10 300 python bench.py --steps 2 --warmup 1 --sqrt-spp $spp --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f M samples/s  %.2f ms/step' % (d['value']/1e6, d['ms_per_step']), {k[:5]: (round(x['avg_us'],1), int(x['launches_per_step'])) for k,x in d['kernels'].items()})")
     echo "$v: $r"
   done
 done
