@@ -55,7 +55,7 @@ struct Pool {
                    //   surface | kBackEmits | kDestIsSample
     float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
     uint32_t nSlots;
-    uint32_t nShards; // min(8, number of shading blocks): shard of a block = blockIdx % nShards
+    uint32_t nShards; // min(kShards, number of shading blocks): shard of a block = blockIdx % nShards
 };
 
 // geometry of one batch of paths
@@ -67,40 +67,29 @@ struct Batch {
     uint32_t totalIds;       // tilesX * tilesY * 64 * nS
 };
 
-// Counters, one per 128-byte line (word index = id * 32):
-//   0..7   path numbers handed out by shard q (a shard = the blocks with blockIdx % 8 == q)
-//   8      slots that have run out of work
-//   16..23 / 24..31  fill of the shadow-ray queue of shard q, double buffered by iteration parity
-constexpr uint32_t kShards = 8;
+// Counters, one per 128-byte line (word index = line * 32), kShards = S:
+//   0..S-1        path numbers handed out by shard q (a shard = the blocks of the shading kernel
+//                 with blockIdx % S == q)
+//   S             slots that have run out of work
+//   S+1..3S       fill of the shadow-ray queue of shard q, double buffered by iteration parity
+// Shards keep the returning atomics of one launch off a common address: one address serves
+// only about 90 of them per microsecond.  (Measured: one atomic per block on 8 shards beats one
+// per wave on 16..256 shards, which also fragments the shadow-ray queues.)
+#ifndef PT_SHARDS
+#define PT_SHARDS 8
+#endif
+constexpr uint32_t kShards = PT_SHARDS;
 constexpr uint32_t kCtrStride = 32;
-constexpr uint32_t kCtrDone = 8;
-constexpr uint32_t kCtrShadow = 16;
-constexpr uint32_t kCtrWords = 32 * kCtrStride;
+constexpr uint32_t kCtrDone = kShards;
+constexpr uint32_t kCtrShadow = kShards + 1;
+constexpr uint32_t kCtrTiming = 3 * kShards + 1; // debug builds only
+constexpr uint32_t kCtrWords = (3 * kShards + 8) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
-// Reserve one unit for every thread of the block that wants one: wave ballots, a
-// prefix sum over the four wave counts in LDS, and ONE atomic per block.
-PT_DEV uint32_t blockReserve(uint32_t* counter, bool want, uint32_t* lds /* 5 words */)
-{
-    const uint64_t mask = __ballot(want);
-    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
-    if (lane == 0)
-        lds[wave] = uint32_t(__popcll(mask));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
-        lds[4] = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = lds[4];
-    for (uint32_t w = 0; w < wave; w++)
-        base += lds[w];
-    return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-}
-
-// The same for two independent reservations at once (two barriers instead of four), for a
-// block of WAVES waves.
+// Two independent reservations for the threads of a block of WAVES waves: one unit for every
+// thread that wants one, by wave ballots, a prefix sum over the wave counts in LDS, and ONE
+// atomic per block and reservation (two barriers).
 template <uint32_t WAVES>
 PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bool wantB,
                           uint32_t* lds /* 2 * (WAVES + 1) words */, uint32_t& posA, uint32_t& posB)
@@ -219,8 +208,9 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
 {
     // the queues this iteration's shadeKernel fills were read by the previous launch of this
     // kernel; this launch reads the other set
-    if (blockIdx.x == 0 && threadIdx.x < kShards)
-        counters[(kCtrShadow + parity * kShards + threadIdx.x) * kCtrStride] = 0;
+    if (blockIdx.x == 0)
+        for (uint32_t q = threadIdx.x; q < kShards; q += 256u)
+            counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
     // per-lane gathers of the walk off the vector memory path
     extern __shared__ float4 ldsGeo[];
@@ -272,7 +262,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     uint32_t dest = 0, destW = 0;
 
     for (;;) {
-        const uint64_t idle = __ballot(!have);
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
         const uint32_t nIdle = uint32_t(__popcll(idle));
         if (nIdle == 64u && pos >= endPos)
             break;
@@ -315,11 +305,11 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
         // repeated while enough lanes are walking; then the waiting surfaces are tested together
         {
             bool walking = have && pending == kInner && cur < sc.n_nodes;
-            while (__ballot(walking) != 0) {
+            while (__builtin_amdgcn_ballot_w64(walking) != 0) {
                 if (walking)
                     nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
                 walking = have && pending == kInner && cur < sc.n_nodes;
-                if (uint32_t(__popcll(__ballot(walking))) < kWalkLanes)
+                if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
                     break;
             }
         }
@@ -390,7 +380,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     do {                                                                               \
         if (laneId() == 0)                                                             \
             for (int k_ = 0; k_ < 12; k_++)                                            \
-                atomicAdd(&counters[(9 + k_ / 4) * kCtrStride + 8 + (k_ % 4) * 2], ptT_acc[k_] >> 8); \
+                atomicAdd(&counters[(kCtrTiming + k_ / 4) * kCtrStride + 8 + (k_ % 4) * 2], ptT_acc[k_] >> 8); \
     } while (0)
 #else
 #define PT_T_DECL()
@@ -566,7 +556,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) shadeKernel(DevScene sc, Pool 
     const uint32_t shard = blockIdx.x % pool.nShards;
     uint32_t pos, local;
     blockReserve2<kShadeWaves>(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
-                  &counters[shard * kCtrStride], want, lds, pos, local);
+                               &counters[shard * kCtrStride], want, lds, pos, local);
     if (haveShadow) {
         const uint32_t e = shard * shadowCap + pos;
         pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
@@ -843,10 +833,10 @@ int runLanes(pt_scene* sc, const RenderArgs& a, Lane* lanes, uint32_t nLanes, hi
                                              "toDirection+emission", "rr+finish", "reserve", "generate", "stores" };
             double tot = 0;
             for (int k = 0; k < 12; k++)
-                tot += w.hostCounters[(9 + k / 4) * kCtrStride + 8 + (k % 4) * 2];
+                tot += w.hostCounters[(kCtrTiming + k / 4) * kCtrStride + 8 + (k % 4) * 2];
             fprintf(stderr, "shade sections (%% of wave cycles, iter %llu):", (unsigned long long)iter);
             for (int k = 0; k < 12; k++)
-                fprintf(stderr, " %s=%.1f", names[k], 100.0 * w.hostCounters[(9 + k / 4) * kCtrStride + 8 + (k % 4) * 2] / tot);
+                fprintf(stderr, " %s=%.1f", names[k], 100.0 * w.hostCounters[(kCtrTiming + k / 4) * kCtrStride + 8 + (k % 4) * 2] / tot);
             fprintf(stderr, "  total=%.3g cycles/wave-launch\n", tot * 256.0 / (double(iter) * (lanes[0].pool.nSlots / 64)));
         }
 #endif
