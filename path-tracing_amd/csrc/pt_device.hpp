@@ -20,7 +20,8 @@ using namespace ptv;
 
 #define PT_DEV __device__ __forceinline__
 
-constexpr uint32_t kInner = 0xFFFFFFFFu; // DevNode.leaf of an inner node
+constexpr uint32_t kInner = 0xFFFFFFFFu; // "no surface": a node step that did not end on a hit leaf
+constexpr uint32_t kInnerBit = 0x80000000u; // DevNode.leaf of an inner node: kInnerBit | index of its second child
 
 // surface kinds (SurfRec word 3 of row 0)
 enum : uint32_t {
@@ -42,7 +43,8 @@ struct DevMesh {
 // Scene tables in HBM.  nodes: 2 x float4 per node = (lo.xyz, hi.x), (hi.y, hi.z,
 // bits escape, bits leaf): `escape` is the node to continue with when this
 // node's subtree is skipped or finished (n_nodes = done); `leaf` is the
-// surface id or kInner.  Inner nodes have their first child at index + 1.
+// surface id, or kInnerBit | second child for an inner node.  Inner nodes have
+// their first child at index + 1.
 // surf: 3 x float4 per surface; triangles (A.xyz, bits kind), (B.xyz, bits
 // mesh), (C.xyz, bits triangle-in-mesh); spheres (centre.xyz, bits kind),
 // (radius, bits sphere, -, -), unused.  surfAttr and matConst repeat, per
@@ -402,6 +404,41 @@ PT_DEV bool aabbHit(V3 lo, V3 hi, const Ray& ray, float amin, float amax)
     return !reject;
 }
 
+// The same test, also giving the distance at which the box is entered (the largest slab
+// entry, or amin; NaN slabs ignored as above).
+PT_DEV bool aabbEntry(V3 lo, V3 hi, const Ray& ray, float amin, float amax, float& entry)
+{
+    bool reject;
+    {
+        float inv = ray.invDirection.x, org = ray.origin.x;
+        bool neg = inv < 0.0f;
+        float admin = ((neg ? hi.x : lo.x) - org) * inv;
+        float admax = ((neg ? lo.x : hi.x) - org) * inv;
+        reject = (admin > amax) | (amin > admax);
+        amin = admin > amin ? admin : amin;
+        amax = admax < amax ? admax : amax;
+    }
+    {
+        float inv = ray.invDirection.y, org = ray.origin.y;
+        bool neg = inv < 0.0f;
+        float admin = ((neg ? hi.y : lo.y) - org) * inv;
+        float admax = ((neg ? lo.y : hi.y) - org) * inv;
+        reject |= (admin > amax) | (amin > admax);
+        amin = admin > amin ? admin : amin;
+        amax = admax < amax ? admax : amax;
+    }
+    {
+        float inv = ray.invDirection.z, org = ray.origin.z;
+        bool neg = inv < 0.0f;
+        float admin = ((neg ? hi.z : lo.z) - org) * inv;
+        float admax = ((neg ? lo.z : hi.z) - org) * inv;
+        reject |= (admin > amax) | (amin > admax);
+        amin = admin > amin ? admin : amin;
+    }
+    entry = amin;
+    return !reject;
+}
+
 // keep a 16-byte record whole: stops the compiler from splitting the load into
 // pieces fetched one early-out at a time
 PT_DEV void keepWhole(float4& v)
@@ -573,7 +610,7 @@ PT_DEV void traverseStep(const DevScene& sc, const float4* __restrict__ nodes, c
     if (COUNT)
         cnt->nodeVisits++;
     if (aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax)) {
-        if (leaf != kInner) {
+        if (!(leaf & kInnerBit)) {
             if (COUNT)
                 cnt->leafTests++;
             if (surfaceTest<DYN>(sc, surf, leaf, ray, amin, amax, best))
@@ -600,8 +637,9 @@ PT_DEV void nodeStep(const float4* __restrict__ nodes, const Ray& ray, float ami
     const uint32_t escape = fbits(n1.z);
     const uint32_t leaf = fbits(n1.w);
     const bool hit = aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax);
-    pendingLeaf = hit ? leaf : kInner;
-    cur = (hit && leaf == kInner) ? cur + 1 : escape;
+    const bool inner = (leaf & kInnerBit) != 0;
+    pendingLeaf = (hit && !inner) ? leaf : kInner;
+    cur = (hit && inner) ? cur + 1 : escape;
 }
 
 PT_DEV HitLite noHit()

@@ -183,7 +183,7 @@ int buildDeviceNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& 
         return fail(PT_ERR_INVALID_ARGUMENT, "acceleration structure has unreachable nodes");
     for (uint64_t k = 0; k < n; k++) {
         const pt_bvh_node& nd = nodes[k];
-        uint32_t leaf = (nd.link % 2 == 0) ? uint32_t(nd.link / 2) : kInner;
+        uint32_t leaf = (nd.link % 2 == 0) ? uint32_t(nd.link / 2) : (kInnerBit | uint32_t(nd.link / 2));
         out[2 * k + 0] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], nd.hi[0]);
         out[2 * k + 1] = make_float4(nd.hi[1], nd.hi[2], __builtin_bit_cast(float, escape[k]), __builtin_bit_cast(float, leaf));
     }

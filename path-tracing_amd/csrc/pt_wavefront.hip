@@ -41,6 +41,7 @@ enum : uint32_t { kNeed = 0, kActive = 1, kDone = 2 };
 constexpr uint32_t kDestIsSample = 0x80000000u;
 constexpr uint32_t kBackEmits = 0x40000000u;
 constexpr uint32_t kLightMask = 0x3FFFFFFFu;
+constexpr uint32_t kRetryIsShadow = 0x80000000u; // retry list entry: a shadow-queue entry rather than a slot
 
 struct Pool {
     float4* o_t;   // ray origin, time
@@ -54,6 +55,8 @@ struct Pool {
     float4* sh_c;  //   what to add if the ray reaches the front side of the chosen light, bits: light
                    //   surface | kBackEmits | kDestIsSample
     float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
+    uint2* retry;  // rays to trace again in storage order: (slot, or kRetryIsShadow | shadow-queue entry; bits of
+                   // the distance beyond which nothing needs to be looked at)
     uint32_t nSlots;
     uint32_t nShards; // min(kShards, number of shading blocks): shard of a block = blockIdx % nShards
 };
@@ -72,6 +75,7 @@ struct Batch {
 //                 with blockIdx % S == q)
 //   S             slots that have run out of work
 //   S+1..3S       fill of the shadow-ray queue of shard q, double buffered by iteration parity
+//   3S+1          rays the nearer-child-first tracing left for the storage-order pass
 // Shards keep the returning atomics of one launch off a common address: one address serves
 // only about 90 of them per microsecond.  (Measured: one atomic per block on 8 shards beats one
 // per wave on 16..256 shards, which also fragments the shadow-ray queues.)
@@ -82,7 +86,8 @@ constexpr uint32_t kShards = PT_SHARDS;
 constexpr uint32_t kCtrStride = 32;
 constexpr uint32_t kCtrDone = kShards;
 constexpr uint32_t kCtrShadow = kShards + 1;
-constexpr uint32_t kCtrTiming = 3 * kShards + 1; // debug builds only
+constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // entries in the retry list
+constexpr uint32_t kCtrTiming = 3 * kShards + 2; // debug builds only
 constexpr uint32_t kCtrWords = (3 * kShards + 8) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
@@ -175,6 +180,48 @@ PT_DEV uint32_t blockSortByClass(uint32_t cls, uint32_t* counts /* WAVES * kClas
     perm[counts[cls * WAVES + wave] + rank] = uint16_t(threadIdx.x);
     __syncthreads();
     return perm[threadIdx.x];
+}
+
+// A shadow ray has found its closest hit: if that is the chosen light, add the prepared
+// contribution to the path's radiance or to its finished sample (reference
+// src/15/pathtracer.cpp:102-107).  Which side of the light: triangles know from the hit test,
+// spheres from the hit point (reference src/15/surface_sphere.hpp:29-34).
+template <bool DYN>
+PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, const Pool& pool, float* __restrict__ samples,
+                         uint32_t entry, const Ray& ray, const HitLite& best, float4 payload, uint32_t dest,
+                         uint32_t destW, V3 destValue)
+{
+    if (best.sid == PT_NO_HIT || best.sid != (fbits(payload.w) & kLightMask))
+        return;
+    bool back = best.backside;
+    const float4 l0 = surf[3 * best.sid + 0];
+    if (fbits(l0.w) > kTriDynamic) {
+        V3 c = v3(l0.x, l0.y, l0.z);
+        if (DYN && fbits(l0.w) == kSphDynamic) {
+            float r;
+            Xform T;
+            uint32_t sphereId;
+            sphereCR(sc, best.sid, ray.time, c, r, T, sphereId);
+        }
+        V3 n = normalize(rayAt(ray, best.a) - c);
+        back = dot(n, -ray.direction) < 0.0f;
+    }
+    V3 add = v3(payload.x, payload.y, payload.z);
+    if (back) {
+        if (!(fbits(payload.w) & kBackEmits))
+            return;
+        const float4 pb = pool.sh_b[entry];
+        add = v3(pb.x, pb.y, pb.z);
+    }
+    V3 sum = destValue + add;
+    if (fbits(payload.w) & kDestIsSample) {
+        float* p = samples + 3 * size_t(dest);
+        p[0] = sum.x;
+        p[1] = sum.y;
+        p[2] = sum.z;
+    } else {
+        pool.rad_p[dest] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(destW));
+    }
 }
 
 // Closest-hit tracing of a stream of rays.  Every wave owns a contiguous run of
@@ -323,44 +370,283 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
             if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
-            } else if (best.sid != PT_NO_HIT && best.sid == (fbits(payload.w) & kLightMask)) {
-                // the chosen light is what the ray sees (reference src/15/pathtracer.cpp:102-107);
-                // which side: triangles know from the hit test, spheres from the hit point
-                // (reference src/15/surface_sphere.hpp:29-34)
-                bool back = best.backside;
-                const float4 l0 = surf[3 * best.sid + 0];
-                if (fbits(l0.w) > kTriDynamic) {
-                    V3 c = v3(l0.x, l0.y, l0.z);
-                    if (DYN && fbits(l0.w) == kSphDynamic) {
-                        float r;
-                        Xform T;
-                        uint32_t sphereId;
-                        sphereCR(sc, best.sid, ray.time, c, r, T, sphereId);
+            } else {
+                shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
+            }
+        }
+    }
+}
+
+// The same job for scenes whose tree lives in memory, visiting the nearer child first.
+//
+// The reference walks the tree in storage order (traceKernel does the same), so a ray tests
+// every box it passes through until the surfaces in front happen to come up.  Going to the
+// nearer child first and skipping what lies beyond the closest hit so far tests a fraction of
+// the boxes.  The result is the reference's whenever it is unambiguous.  The reference accepts
+// a surface when it reaches it, unless a box above it is entered (by the box test's
+// arithmetic) beyond the closest distance accepted before; and after the closest surface it
+// accepts only an exact tie.  So the closest surface found here is the reference's result if
+// no other surface is hit before
+//     limit = max(its distance, entry distance of the boxes above it) * (1 + kTieBand);
+// the band also covers the rounding difference between a box's entry distance and a surface's
+// hit distance inside that box, which is what allows skipping subtrees entered beyond the limit.
+// A ray whose result is ambiguous by this rule, or that needs more stack than a lane has, is
+// put on the retry list and traced in storage order by traceRetryKernel.
+//
+// Per lane: the node it stands on (its box is known to be hit; `link` is the node's leaf field,
+// `gate` the largest entry distance on the way down), and a stack of (node, gate) in LDS.
+#ifndef PT_STACK_DEPTH
+#define PT_STACK_DEPTH 20
+#endif
+constexpr uint32_t kStackDepth = PT_STACK_DEPTH;
+constexpr float kTieBand = 1.0e-4f;
+
+template <bool DYN>
+__global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
+                                                          float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
+{
+    __shared__ uint2 stack[kStackDepth][256];
+    if (blockIdx.x == 0)
+        for (uint32_t q = threadIdx.x; q < kShards; q += 256u)
+            counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
+    const float4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ surf = sc.surf;
+    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
+    const uint32_t lane = laneId();
+    const uint64_t below = (1ull << lane) - 1ull;
+    const bool shadow = waveIdx >= slotWaves;
+    uint32_t pos, endPos;
+    uint32_t itemBase = 0;
+    if (!shadow) {
+        pos = waveIdx * (64u * kItemsPerLane);
+        endPos = min(pos + 64u * kItemsPerLane, pool.nSlots);
+    } else {
+        pos = (waveIdx - slotWaves) * (64u * kItemsPerLane);
+        const uint32_t shard = pos / shadowCap;
+        if (shard >= kShards)
+            return;
+        const uint32_t fill = counters[(kCtrShadow + (parity ^ 1) * kShards + shard) * kCtrStride];
+        itemBase = shard * shadowCap;
+        pos -= itemBase;
+        endPos = min(pos + 64u * kItemsPerLane, fill);
+    }
+    if (pos >= endPos)
+        return;
+
+    bool have = false;
+    uint32_t item = 0;
+    Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
+    uint32_t cur = 0, link = 0, top = 0;
+    float gate = 0.0f, cull = kFltMax, otherT = kFltMax, bestGate = 0.0f;
+    bool overflow = false;
+    HitLite best = noHit();
+    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    V3 destValue = v3(0.0f);
+    uint32_t dest = 0, destW = 0;
+    const uint32_t kDoneNode = 0xFFFFFFFFu; // cur of a lane whose walk is over
+
+    for (;;) {
+        const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
+        const uint32_t nIdle = uint32_t(__popcll(idle));
+        if (nIdle == 64u && pos >= endPos)
+            break;
+        if (pos < endPos && (nIdle >= kRefillLanes || nIdle == 64u)) {
+            const uint32_t cand = pos + uint32_t(__popcll(idle & below));
+            if (!have && cand < endPos) {
+                item = cand;
+                if (!shadow) {
+                    const float4 d_s = pool.d_s[item];
+                    if (((fbits(d_s.w) >> 16) & 3u) == kActive) {
+                        const float4 o_t = pool.o_t[item];
+                        ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+                        have = true;
                     }
-                    V3 n = normalize(rayAt(ray, best.a) - c);
-                    back = dot(n, -ray.direction) < 0.0f;
-                }
-                V3 add = v3(payload.x, payload.y, payload.z);
-                bool doAdd = true;
-                if (back) {
-                    doAdd = (fbits(payload.w) & kBackEmits) != 0;
-                    if (doAdd) {
-                        const float4 pb = pool.sh_b[itemBase + item];
-                        add = v3(pb.x, pb.y, pb.z);
-                    }
-                }
-                if (doAdd) {
-                    V3 sum = destValue + add;
+                } else {
+                    const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
+                    payload = pool.sh_c[itemBase + item];
+                    dest = fbits(sd.w);
                     if (fbits(payload.w) & kDestIsSample) {
-                        float* p = samples + 3 * size_t(dest);
-                        p[0] = sum.x;
-                        p[1] = sum.y;
-                        p[2] = sum.z;
+                        const float* p = samples + 3 * size_t(dest);
+                        destValue = v3(p[0], p[1], p[2]);
                     } else {
-                        pool.rad_p[dest] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(destW));
+                        const float4 r = pool.rad_p[dest];
+                        destValue = v3(r.x, r.y, r.z);
+                        destW = fbits(r.w);
+                    }
+                    ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
+                    have = true;
+                }
+                if (have) {
+                    best = noHit();
+                    cull = kFltMax;
+                    otherT = kFltMax;
+                    bestGate = 0.0f;
+                    overflow = false;
+                    top = 0;
+                    // the root
+                    cur = kDoneNode;
+                    if (sc.n_nodes > 0) {
+                        const float4 n0 = nodes[0], n1 = nodes[1];
+                        if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, gate)) {
+                            cur = 0;
+                            link = fbits(n1.w);
+                        }
                     }
                 }
             }
+            pos = min(pos + nIdle, endPos);
+        }
+        // inner nodes: test both children, go to the nearer one that is hit, keep the other;
+        // repeated while enough lanes stand on inner nodes
+        {
+            bool walking = have && cur != kDoneNode && (link & kInnerBit);
+            while (__builtin_amdgcn_ballot_w64(walking) != 0) {
+                if (walking) {
+                    const uint32_t c1 = cur + 1, c2 = link & ~kInnerBit;
+                    float4 a0 = nodes[2 * c1 + 0], a1 = nodes[2 * c1 + 1];
+                    float4 b0 = nodes[2 * c2 + 0], b1 = nodes[2 * c2 + 1];
+                    keepWhole(a0);
+                    keepWhole(a1);
+                    keepWhole(b0);
+                    keepWhole(b1);
+                    float e1, e2;
+                    const bool h1 = aabbEntry(v3(a0.x, a0.y, a0.z), v3(a0.w, a1.x, a1.y), ray, 0.0001f, cull, e1);
+                    const bool h2 = aabbEntry(v3(b0.x, b0.y, b0.z), v3(b0.w, b1.x, b1.y), ray, 0.0001f, cull, e2);
+                    const float g1 = fmaxf(gate, e1), g2 = fmaxf(gate, e2);
+                    const bool firstNear = e1 <= e2;
+                    if (h1 && h2) {
+                        if (top < kStackDepth) {
+                            stack[top][threadIdx.x] = make_uint2(firstNear ? c2 : c1, fbits(firstNear ? g2 : g1));
+                            top++;
+                        } else {
+                            overflow = true;
+                        }
+                    }
+                    const bool take1 = h1 && (!h2 || firstNear);
+                    if (h1 || h2) {
+                        cur = take1 ? c1 : c2;
+                        gate = take1 ? g1 : g2;
+                        link = fbits(take1 ? a1.w : b1.w);
+                    } else {
+                        cur = kDoneNode; // nothing below: take the next kept node
+                    }
+                    if (overflow)
+                        cur = kDoneNode, top = 0;
+                }
+                // a lane with nothing below pops the nearest kept node still within the limit
+                if (have && cur == kDoneNode && top > 0) {
+                    while (top > 0) {
+                        top--;
+                        const uint2 e = stack[top][threadIdx.x];
+                        if (!(__uint_as_float(e.y) > cull)) {
+                            cur = e.x;
+                            gate = __uint_as_float(e.y);
+                            link = fbits(nodes[2 * cur + 1].w);
+                            break;
+                        }
+                    }
+                }
+                walking = have && cur != kDoneNode && (link & kInnerBit);
+                if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
+                    break;
+            }
+        }
+        // leaves: test the surface, then take the next kept node
+        if (have && cur != kDoneNode && !(link & kInnerBit)) {
+            HitLite h;
+            if (surfaceTest<DYN>(sc, surf, link, ray, 0.0001f, cull, h)) {
+                if (best.sid == PT_NO_HIT || h.a < best.a) {
+                    if (best.sid != PT_NO_HIT)
+                        otherT = fminf(otherT, best.a);
+                    best = h;
+                    bestGate = gate;
+                    cull = fmaxf(best.a, bestGate) * (1.0f + kTieBand);
+                    if (!(cull < kFltMax))
+                        cull = kFltMax;
+                } else {
+                    otherT = fminf(otherT, h.a);
+                }
+            }
+            cur = kDoneNode;
+            while (top > 0) {
+                top--;
+                const uint2 e = stack[top][threadIdx.x];
+                if (!(__uint_as_float(e.y) > cull)) {
+                    cur = e.x;
+                    gate = __uint_as_float(e.y);
+                    link = fbits(nodes[2 * cur + 1].w);
+                    break;
+                }
+            }
+        }
+        if (have && cur == kDoneNode && top == 0) {
+            have = false;
+            const bool ambiguous = overflow || (best.sid != PT_NO_HIT && otherT <= cull);
+            // the lanes finishing together put their ambiguous rays on the retry list: one atomic
+            const uint64_t am = __builtin_amdgcn_ballot_w64(ambiguous);
+            if (am != 0) {
+                uint32_t base = 0;
+                if (lane == uint32_t(__ffsll((long long)am) - 1))
+                    base = atomicAdd(&counters[kCtrRetry * kCtrStride], uint32_t(__popcll(am)));
+                base = uint32_t(__shfl(int(base), __ffsll((long long)am) - 1));
+                if (ambiguous) {
+                    // what was found bounds the search of the second pass (same band once more)
+                    float bound = best.sid != PT_NO_HIT ? cull * (1.0f + kTieBand) : kFltMax;
+                    if (!(bound < kFltMax))
+                        bound = kFltMax;
+                    pool.retry[base + uint32_t(__popcll(am & below))]
+                        = make_uint2(shadow ? (kRetryIsShadow | (itemBase + item)) : item, fbits(bound));
+                }
+            }
+            if (ambiguous) {
+                // settled by traceRetryKernel
+            } else if (!shadow) {
+                pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
+                                            fbits(best.a), fbits(best.u), fbits(best.v));
+            } else {
+                shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
+            }
+        }
+    }
+}
+
+// The rays traceOrderedKernel left over, each traced to completion in storage order (reference
+// src/15/bvh.hpp:183-213) by one lane, starting from the distance bound the first pass found:
+// boxes entered beyond it hold nothing that could be accepted after the surfaces within it, so
+// the walk sees the same surfaces win as one that starts unbounded.  They are few (a percent
+// of the rays or less), so the list fits the chip many times over.
+template <bool DYN>
+__global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters,
+                                                        float* __restrict__ samples)
+{
+    const uint32_t n = counters[kCtrRetry * kCtrStride];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint2 entry = pool.retry[i];
+        const uint32_t e = entry.x;
+        const float bound = __uint_as_float(entry.y);
+        if (!(e & kRetryIsShadow)) {
+            const float4 o_t = pool.o_t[e], d_s = pool.d_s[e];
+            const Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+            const HitLite best = closestHit<false, DYN>(sc, ray, 0.0001f, bound, nullptr);
+            pool.hit[e] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
+                                     fbits(best.a), fbits(best.u), fbits(best.v));
+        } else {
+            const uint32_t q = e & ~kRetryIsShadow;
+            const float4 so = pool.sh_o[q], sd = pool.sh_d[q], payload = pool.sh_c[q];
+            const uint32_t dest = fbits(sd.w);
+            V3 destValue;
+            uint32_t destW = 0;
+            if (fbits(payload.w) & kDestIsSample) {
+                const float* p = samples + 3 * size_t(dest);
+                destValue = v3(p[0], p[1], p[2]);
+            } else {
+                const float4 r = pool.rad_p[dest];
+                destValue = v3(r.x, r.y, r.z);
+                destW = fbits(r.w);
+            }
+            const Ray ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
+            const HitLite best = closestHit<false, DYN>(sc, ray, 0.0001f, bound, nullptr);
+            shadowArrive<DYN>(sc, sc.surf, pool, samples, q, ray, best, payload, dest, destW, destValue);
         }
     }
 }
@@ -402,6 +688,8 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) shadeKernel(DevScene sc, Pool 
     __shared__ uint32_t sortCounts[kShadeWaves * kClasses];
     __shared__ uint16_t sortPerm[kShadeBlock];
     const PathParams pp = a.pp;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        counters[kCtrRetry * kCtrStride] = 0; // the retry list of this iteration has been worked off
     PT_T_DECL();
     // The block owns a window of kShadeBlock slots (the grid covers the slots exactly).  Which
     // thread takes which slot of the window is decided by what the slot needs: a new path
@@ -657,7 +945,7 @@ uint32_t shadowCapOf(uint32_t nSlots)
 
 size_t poolBytes(uint32_t n)
 {
-    return size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * 16 * 4;
+    return size_t(n) * (16 * 5 + 8 + 8) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 8);
 }
 
 Pool carvePool(void* base, uint32_t n)
@@ -680,6 +968,7 @@ Pool carvePool(void* base, uint32_t n)
     p.sh_c = static_cast<float4*>(take(q * 16));
     p.sh_b = static_cast<float4*>(take(q * 16));
     p.key = static_cast<uint2*>(take(size_t(n) * 8));
+    p.retry = static_cast<uint2*>(take((size_t(n) + q) * 8));
     p.nSlots = n;
     p.nShards = std::min<uint32_t>(kShards, n / kShadeBlock);
     return p;
@@ -757,9 +1046,23 @@ void launchTrace(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t 
     const uint32_t shadowWaves = (shadowCap * kShards / run + 3u) / 4u * 4u;
     const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
     const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
+    // scenes in memory: nearer child first, then the few rays that leaves open in storage order
+    static const bool referenceOrder = [] {
+        const char* v = std::getenv("PT_TRAVERSAL");
+        return v && std::string(v) == "reference";
+    }();
+    const bool ordered = !LDS && !referenceOrder;
     sc->kt.begin(KernelTimes::kTrace, stream);
-    hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, ln.counters, parity,
-                       ln.samples, shadowCap, slotWaves);
+    if (ordered) {
+        hipLaunchKernelGGL((traceOrderedKernel<DYN>), gridTrace, block, 0, stream, sc->dev, pool, ln.counters, parity,
+                           ln.samples, shadowCap, slotWaves);
+        const uint32_t retryBlocks = std::min<uint32_t>(2048u, (pool.nSlots + shadowCap * kShards + 255u) / 256u);
+        hipLaunchKernelGGL((traceRetryKernel<DYN>), dim3(retryBlocks), block, 0, stream, sc->dev, pool, ln.counters,
+                           ln.samples);
+    } else {
+        hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, ln.counters, parity,
+                           ln.samples, shadowCap, slotWaves);
+    }
     sc->kt.end(stream);
 }
 
