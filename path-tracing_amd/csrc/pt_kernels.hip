@@ -190,6 +190,27 @@ int buildDeviceNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& 
     return PT_OK;
 }
 
+// Per inner node k, one 64-byte row with what a step of the nearer-child-first walk needs:
+// the boxes of both children and their leaf fields (surface id, or kInnerBit | node number).
+// Rows of leaf nodes are unused.
+void buildWideNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& out)
+{
+    out.assign(4 * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    auto leafField = [&](uint64_t c) {
+        return (nodes[c].link % 2 == 0) ? uint32_t(nodes[c].link / 2) : (kInnerBit | uint32_t(c));
+    };
+    for (uint64_t k = 0; k < n; k++) {
+        if (nodes[k].link % 2 == 0)
+            continue;
+        const uint64_t c1 = k + 1, c2 = nodes[k].link / 2;
+        const pt_bvh_node &a = nodes[c1], &b = nodes[c2];
+        out[4 * k + 0] = make_float4(a.lo[0], a.lo[1], a.lo[2], a.hi[0]);
+        out[4 * k + 1] = make_float4(a.hi[1], a.hi[2], b.lo[0], b.lo[1]);
+        out[4 * k + 2] = make_float4(b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
+        out[4 * k + 3] = make_float4(__builtin_bit_cast(float, leafField(c1)), __builtin_bit_cast(float, leafField(c2)), 0.0f, 0.0f);
+    }
+}
+
 int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_params* p, const void* out, RenderArgs& a)
 {
     if (!scene || !camera || !p || !out)
@@ -306,6 +327,8 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     rc = buildDeviceNodes(d->bvh_nodes, d->n_bvh_nodes, nodes);
     if (rc != PT_OK)
         return rc;
+    std::vector<float4> wide;
+    buildWideNodes(d->bvh_nodes, d->n_bvh_nodes, wide);
 
     std::vector<DevMesh> meshes(d->n_meshes);
     for (uint64_t i = 0; i < d->n_meshes; i++) {
@@ -407,6 +430,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
         return code;
     };
     float4* dNodes = nullptr;
+    float4* dWide = nullptr;
     float4* dSurf = nullptr;
     uint4* dSurfAttr = nullptr;
     float4* dMatConst = nullptr;
@@ -418,6 +442,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     pt_texture* dTex = nullptr;
     pt_animation* dAnims = nullptr;
     if ((rc = upload(nodes.data(), nodes.size(), &dNodes, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(wide.data(), wide.size(), &dWide, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(surf.data(), surf.size(), &dSurf, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(surfAttr.data(), surfAttr.size(), &dSurfAttr, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(matConst.data(), matConst.size(), &dMatConst, sc->owned)) != PT_OK) return bail(rc);
@@ -434,7 +459,9 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     if ((rc = upload(d->texels, d->n_texels, &dTexels, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->animations, d->n_animations, &dAnims, sc->owned)) != PT_OK) return bail(rc);
     sc->nodes = dNodes;
+    sc->wide = dWide;
     dev.nodes = dNodes;
+    dev.wide = dWide;
     dev.surf = dSurf;
     dev.surfAttr = dSurfAttr;
     dev.matConst = dMatConst;
@@ -480,6 +507,8 @@ int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_no
     DeviceGuard g(scene->device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(scene->nodes, dn.data(), dn.size() * sizeof(float4), hipMemcpyHostToDevice));
+    buildWideNodes(nodes, n_nodes, dn);
+    HIP_TRY(hipMemcpy(scene->wide, dn.data(), dn.size() * sizeof(float4), hipMemcpyHostToDevice));
     return PT_OK;
 }
 

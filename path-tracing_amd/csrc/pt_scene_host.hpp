@@ -144,6 +144,7 @@ struct pt_scene {
     ptd::DevScene dev;
     std::vector<void*> owned; // every device allocation of the scene
     float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
+    float4* wide = nullptr;   // likewise
     uint64_t n_surfaces = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;

@@ -390,13 +390,16 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
 //     limit = max(its distance, entry distance of the boxes above it) * (1 + kTieBand);
 // the band also covers the rounding difference between a box's entry distance and a surface's
 // hit distance inside that box, which is what allows skipping subtrees entered beyond the limit.
-// A ray whose result is ambiguous by this rule, or that needs more stack than a lane has, is
-// put on the retry list and traced in storage order by traceRetryKernel.
+// A ray whose result is ambiguous by this rule is put on the retry list and traced in storage
+// order by traceRetryKernel; so is a ray that had to leave out a subtree for lack of stack,
+// unless that subtree is entered beyond the limit.
 //
-// Per lane: the node it stands on (its box is known to be hit; `link` is the node's leaf field,
-// `gate` the largest entry distance on the way down), and a stack of (node, gate) in LDS.
+// Per lane: the node it stands on, as its leaf field `link` (a surface, or kInnerBit | node
+// number; its box is known to be hit), `gate` = the largest entry distance on the way down,
+// and a stack of (link, gate) in LDS.  A step at an inner node reads one 64-byte row with
+// the boxes and leaf fields of both children.
 #ifndef PT_STACK_DEPTH
-#define PT_STACK_DEPTH 20
+#define PT_STACK_DEPTH 16
 #endif
 constexpr uint32_t kStackDepth = PT_STACK_DEPTH;
 constexpr float kTieBand = 1.0e-4f;
@@ -410,6 +413,7 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
         for (uint32_t q = threadIdx.x; q < kShards; q += 256u)
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
     const float4* __restrict__ nodes = sc.nodes;
+    const float4* __restrict__ wide = sc.wide;
     const float4* __restrict__ surf = sc.surf;
     const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
@@ -436,14 +440,14 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
     bool have = false;
     uint32_t item = 0;
     Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
-    uint32_t cur = 0, link = 0, top = 0;
+    uint32_t link = 0, top = 0;
+    bool walkOver = true; // nothing left to visit
     float gate = 0.0f, cull = kFltMax, otherT = kFltMax, bestGate = 0.0f;
-    bool overflow = false;
+    float dropGate = __builtin_huge_valf(); // nearest entry distance of a subtree that found no room on the stack
     HitLite best = noHit();
     float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     V3 destValue = v3(0.0f);
     uint32_t dest = 0, destW = 0;
-    const uint32_t kDoneNode = 0xFFFFFFFFu; // cur of a lane whose walk is over
 
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
@@ -481,15 +485,15 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
                     cull = kFltMax;
                     otherT = kFltMax;
                     bestGate = 0.0f;
-                    overflow = false;
+                    dropGate = __builtin_huge_valf();
                     top = 0;
                     // the root
-                    cur = kDoneNode;
+                    walkOver = true;
                     if (sc.n_nodes > 0) {
                         const float4 n0 = nodes[0], n1 = nodes[1];
                         if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, gate)) {
-                            cur = 0;
-                            link = fbits(n1.w);
+                            walkOver = false;
+                            link = (fbits(n1.w) & kInnerBit) ? kInnerBit : fbits(n1.w); // inner root = node 0
                         }
                     }
                 }
@@ -499,60 +503,58 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
         // inner nodes: test both children, go to the nearer one that is hit, keep the other;
         // repeated while enough lanes stand on inner nodes
         {
-            bool walking = have && cur != kDoneNode && (link & kInnerBit);
+            bool walking = have && !walkOver && (link & kInnerBit);
             while (__builtin_amdgcn_ballot_w64(walking) != 0) {
                 if (walking) {
-                    const uint32_t c1 = cur + 1, c2 = link & ~kInnerBit;
-                    float4 a0 = nodes[2 * c1 + 0], a1 = nodes[2 * c1 + 1];
-                    float4 b0 = nodes[2 * c2 + 0], b1 = nodes[2 * c2 + 1];
-                    keepWhole(a0);
-                    keepWhole(a1);
-                    keepWhole(b0);
-                    keepWhole(b1);
+                    const uint32_t k = link & ~kInnerBit;
+                    float4 w0 = wide[4 * k + 0], w1 = wide[4 * k + 1], w2 = wide[4 * k + 2], w3 = wide[4 * k + 3];
+                    keepWhole(w0);
+                    keepWhole(w1);
+                    keepWhole(w2);
+                    keepWhole(w3);
                     float e1, e2;
-                    const bool h1 = aabbEntry(v3(a0.x, a0.y, a0.z), v3(a0.w, a1.x, a1.y), ray, 0.0001f, cull, e1);
-                    const bool h2 = aabbEntry(v3(b0.x, b0.y, b0.z), v3(b0.w, b1.x, b1.y), ray, 0.0001f, cull, e2);
+                    const bool h1 = aabbEntry(v3(w0.x, w0.y, w0.z), v3(w0.w, w1.x, w1.y), ray, 0.0001f, cull, e1);
+                    const bool h2 = aabbEntry(v3(w1.z, w1.w, w2.x), v3(w2.y, w2.z, w2.w), ray, 0.0001f, cull, e2);
                     const float g1 = fmaxf(gate, e1), g2 = fmaxf(gate, e2);
                     const bool firstNear = e1 <= e2;
                     if (h1 && h2) {
                         if (top < kStackDepth) {
-                            stack[top][threadIdx.x] = make_uint2(firstNear ? c2 : c1, fbits(firstNear ? g2 : g1));
+                            stack[top][threadIdx.x] = make_uint2(fbits(firstNear ? w3.y : w3.x), fbits(firstNear ? g2 : g1));
                             top++;
                         } else {
-                            overflow = true;
+                            // no room: leave the farther subtree out; the result stands if it turns
+                            // out to lie beyond the limit anyway
+                            dropGate = fminf(dropGate, firstNear ? g2 : g1);
                         }
                     }
                     const bool take1 = h1 && (!h2 || firstNear);
                     if (h1 || h2) {
-                        cur = take1 ? c1 : c2;
                         gate = take1 ? g1 : g2;
-                        link = fbits(take1 ? a1.w : b1.w);
+                        link = fbits(take1 ? w3.x : w3.y);
                     } else {
-                        cur = kDoneNode; // nothing below: take the next kept node
+                        walkOver = true; // nothing below: take the next kept node
                     }
-                    if (overflow)
-                        cur = kDoneNode, top = 0;
                 }
                 // a lane with nothing below pops the nearest kept node still within the limit
-                if (have && cur == kDoneNode && top > 0) {
+                if (have && walkOver) {
                     while (top > 0) {
                         top--;
                         const uint2 e = stack[top][threadIdx.x];
                         if (!(__uint_as_float(e.y) > cull)) {
-                            cur = e.x;
+                            link = e.x;
                             gate = __uint_as_float(e.y);
-                            link = fbits(nodes[2 * cur + 1].w);
+                            walkOver = false;
                             break;
                         }
                     }
                 }
-                walking = have && cur != kDoneNode && (link & kInnerBit);
+                walking = have && !walkOver && (link & kInnerBit);
                 if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
                     break;
             }
         }
         // leaves: test the surface, then take the next kept node
-        if (have && cur != kDoneNode && !(link & kInnerBit)) {
+        if (have && !walkOver && !(link & kInnerBit)) {
             HitLite h;
             if (surfaceTest<DYN>(sc, surf, link, ray, 0.0001f, cull, h)) {
                 if (best.sid == PT_NO_HIT || h.a < best.a) {
@@ -567,21 +569,21 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
                     otherT = fminf(otherT, h.a);
                 }
             }
-            cur = kDoneNode;
+            walkOver = true;
             while (top > 0) {
                 top--;
                 const uint2 e = stack[top][threadIdx.x];
                 if (!(__uint_as_float(e.y) > cull)) {
-                    cur = e.x;
+                    link = e.x;
                     gate = __uint_as_float(e.y);
-                    link = fbits(nodes[2 * cur + 1].w);
+                    walkOver = false;
                     break;
                 }
             }
         }
-        if (have && cur == kDoneNode && top == 0) {
+        if (have && walkOver) {
             have = false;
-            const bool ambiguous = overflow || (best.sid != PT_NO_HIT && otherT <= cull);
+            const bool ambiguous = (best.sid != PT_NO_HIT && otherT <= cull) || dropGate <= cull;
             // the lanes finishing together put their ambiguous rays on the retry list: one atomic
             const uint64_t am = __builtin_amdgcn_ballot_w64(ambiguous);
             if (am != 0) {
