@@ -41,13 +41,13 @@ def workload(name):
     if name == "cornell":
         scene = pt.LoadedScene(os.path.join(golden, "cornell_glossy.ptscene"))
         cam = pt.load_camera(os.path.join(golden, "cornell_wide.ptcam"))
-        return scene, cam, "cornell-box glossy+MIS 1920x1080 1024spp", 32
+        return scene, cam, "cornell-box glossy+MIS 1920x1080 1024spp (BASELINE configs[1])", 32
     if name.startswith("mesh"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import scenes
         n = int(name[4:] or 1000)
         s, cam = scenes.big_mesh_scene(n)
-        return s, cam, "displaced grid %d triangles 1920x1080 256spp" % (2 * n * n + 2), 16
+        return s, cam, "displaced grid %d triangles 1920x1080 256spp (BASELINE configs[2])" % (2 * n * n + 2), 16
     raise SystemExit("unknown workload " + name)
 
 
@@ -71,10 +71,16 @@ def measured_traffic(workload_name, kernel):
         return None, "no PMC pass committed for this workload"
     with open(path) as f:
         t = json.load(f)
-    k = t.get("kernels", {}).get(kernel)
-    if not k:
+    ks = t.get("kernels", {})
+    if kernel == "traceKernel":
+        # one tracing step of the renderer is one launch of traceKernel (scenes held in LDS), or a launch of
+        # traceOrderedKernel followed by one of traceRetryKernel (scenes in memory)
+        rows = [v for name, v in ks.items() if name.startswith("trace")]
+    else:
+        rows = [ks[kernel]] if kernel in ks else []
+    if not rows:
         return None, "PMC file has no row for " + kernel
-    return k["hbm_bytes_per_launch"], t.get("how", "")
+    return sum(r["hbm_bytes_per_launch"] for r in rows), t.get("how", "")
 
 
 def cpu_baseline(scene, cam, width, height, seed):
@@ -223,6 +229,10 @@ def main():
             if launches:
                 kernels[name] = {"launches_per_step": launches / args.steps, "avg_us": total_ms / launches * 1e3,
                                  "ms_per_step": total_ms / args.steps}
+                if name in kernel_bytes_ps:
+                    per_launch = launch_samples * args.steps / launches
+                    kernels[name]["algorithmic_GBps"] = kernel_bytes_ps[name] * per_launch / (total_ms / launches * 1e-3) / 1e9
+                    kernels[name]["hbm_bytes_per_launch"] = measured_traffic(args.workload, name)[0]
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         dk = kernels[dominant]
         # one launch of the dominant kernel advances (samples of a render / its launches per render) samples
