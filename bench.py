@@ -36,18 +36,34 @@ VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak, TFLOP/s
 
 
 def workload(name):
+    """(scene, camera, label, sqrt_spp, extra): extra may hold width, height, samples (a range of the
+    sqrt_spp^2 strata), max_path_segments, frames (list of shutter intervals, one render each per step)
+    and the sharding mode for more than one GPU."""
     import path_tracing_amd as pt
     golden = os.path.join(ROOT, "tests", "golden")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     if name == "cornell":
         scene = pt.LoadedScene(os.path.join(golden, "cornell_glossy.ptscene"))
         cam = pt.load_camera(os.path.join(golden, "cornell_wide.ptcam"))
-        return scene, cam, "cornell-box glossy+MIS 1920x1080 1024spp (BASELINE configs[1])", 32
+        return scene, cam, "cornell-box glossy+MIS 1920x1080 1024spp (BASELINE configs[1])", 32, {}
     if name.startswith("mesh"):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import scenes
         n = int(name[4:] or 1000)
         s, cam = scenes.big_mesh_scene(n)
-        return s, cam, "displaced grid %d triangles 1920x1080 256spp (BASELINE configs[2])" % (2 * n * n + 2), 16
+        return s, cam, "displaced grid %d triangles 1920x1080 256spp (BASELINE configs[2])" % (2 * n * n + 2), 16, {}
+    if name == "textured":
+        # every material, image/checker/transformer textures, normal and opacity maps, image environment map
+        import scenes
+        s, cam, _ = scenes.build("materials")
+        return s, cam, "textured multi-material 3840x2160 512spp max depth 32 (BASELINE configs[3])", 23, {
+            "width": 3840, "height": 2160, "samples": (0, 512), "max_path_segments": 32, "sharding": "tiles"}
+    if name == "frames":
+        # two-key animated spheres, meshes, lights and camera; a new tree per frame (shutter 1/25 s)
+        import scenes
+        s, cam, _ = scenes.build("animated")
+        frames = [(f / 25.0, (f + 1) / 25.0) for f in range(8)]
+        return s, cam, "animated scene, 8 of 240 frames per step, 1920x1080 128spp (BASELINE configs[4])", 12, {
+            "samples": (0, 128), "frames": frames, "sharding": "frames"}
     raise SystemExit("unknown workload " + name)
 
 
@@ -148,15 +164,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    scene, cam, label, default_sqrt = workload(args.workload)
+    scene, cam, label, default_sqrt, extra = workload(args.workload)
     sqrt_spp = args.sqrt_spp or default_sqrt
-    W, H = args.width, args.height
-    spp = sqrt_spp * sqrt_spp
+    W, H = extra.get("width", args.width), extra.get("height", args.height)
+    samples = extra.get("samples") if not args.sqrt_spp else None
+    spp = (samples[1] - samples[0]) if samples else sqrt_spp * sqrt_spp
+    frames = extra.get("frames")
+    mode = extra.get("sharding", "batches")
     dev = pt.DeviceScene(scene, device=local_rank)
     out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     # every rank renders its own batch of samples of the same frame (its own seed)
-    params = pt.make_params(W, H, sqrt_spp, seed=42)
+    params = pt.make_params(W, H, sqrt_spp, seed=42, samples=samples,
+                            max_path_segments=extra.get("max_path_segments", 0))
 
     from path_tracing_amd import distributed as shard
     events = []
@@ -168,18 +188,27 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        if world == 1:
+        if frames:
+            # this rank's frames, round robin: tree over the frame's shutter interval (host builder),
+            # upload, render; no exchange
+            for f in shard.plan_frames(len(frames), world, rank):
+                t0f, t1f = frames[f]
+                dev.update_bvh(scene.build_bvh(t0f, t1f))
+                render(pt.make_params(W, H, sqrt_spp, seed=42 + f, t0=t0f, t1=t1f, samples=samples), out)
+        elif world == 1:
             render(params, out)
         else:
-            # the render of this rank's batch, then the exchange: one RCCL sum-reduce to rank 0
-            for p in shard.shard_params(params, "batches", world, rank):
+            # this rank's share (its own batch of samples, or its tiles), then one RCCL sum-reduce to rank 0
+            if mode == "tiles":
+                out.zero_()
+            for p in shard.shard_params(params, mode, world, rank, tile=256):
                 render(p, out)
         if timed:
             e1.record(stream)
             events.append((e0, e1))
-        if world > 1:
+        if world > 1 and not frames:
             dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
+            if rank == 0 and mode == "batches":
                 out.div_(float(spp * world))
 
     def barrier():
@@ -210,14 +239,17 @@ def main():
 
     result = None
     if rank == 0:
-        total_samples = float(W) * H * spp * world * args.steps
+        n_renders = len(frames) if frames else (world if mode == "batches" else 1)
+        total_samples = float(W) * H * spp * n_renders * args.steps
         value = total_samples / elapsed
         # work counts of the reference algorithm on this scene (instrumented kernel, reduced spp)
         cparams = pt.make_params(W // 4, H // 4, min(sqrt_spp, 4), seed=42)
         _, cnt = dev.render_counted(cam, cparams)
         cnt = cnt.as_dict()
         bytes_ps, flops_ps = algorithmic_per_sample(cnt, 0)
-        launch_samples = float(W) * H * spp
+        launch_samples = float(W) * H * spp * (len(shard.plan_frames(len(frames), world, 0)) if frames else 1)
+        if world > 1 and mode == "tiles":
+            launch_samples /= world
         n_s = max(cnt["path_samples"], 1)
         # the reference algorithm's bytes, split by the kernel that does that part of the work
         kernel_bytes_ps = {
@@ -244,11 +276,14 @@ def main():
         result = {
             "metric": "path samples/sec at 1080p", "value": value, "unit": "path samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if mode == "batches" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label, "width": W, "height": H, "spp": spp, "samples_per_step": launch_samples * world,
-                       "sharding": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp
-                       if world > 1 else "single GPU"},
+            "config": {"workload": label, "width": W, "height": H, "spp": spp,
+                       "samples_per_step": total_samples / args.steps,
+                       "sharding": "single GPU" if world == 1 else
+                       {"batches": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp,
+                        "tiles": "256x256 tiles interleaved over GPUs, RCCL sum-reduce to rank 0",
+                        "frames": "frames round robin over GPUs, no exchange"}[mode]},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dominant, "kernel_avg_us": dk["avg_us"],

@@ -22,7 +22,6 @@ Nothing here renders: the caller passes a `render(params, out)` callable (the GP
 production, the CPU oracle in the gloo tests).
 """
 from . import abi
-from .api import make_params
 
 
 def plan_tiles(width, height, world, rank, tile=32):
@@ -52,9 +51,7 @@ def plan_frames(n_frames, world, rank):
 def shard_params(base, mode, world, rank, tile=32):
     """The pt_render_params of every render call this rank makes for one image."""
     def clone(**kw):
-        p = make_params(base.width, base.height, base.sqrt_spp, seed=base.seed, t0=base.t0, t1=base.t1,
-                        flags=base.flags, max_path_segments=base.max_path_segments,
-                        rr_start_segment=base.rr_start_segment)
+        p = abi.pt_render_params.from_buffer_copy(base)
         for k, v in kw.items():
             setattr(p, k, v)
         return p
