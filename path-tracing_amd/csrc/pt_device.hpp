@@ -56,7 +56,7 @@ struct DevScene {
     const float4* wide;      // per inner node 4 x float4: boxes of both children (lo1.xyz hi1.x | hi1.yz lo2.xy |
                              // lo2.z hi2.xyz) and their leaf fields (surface id, or kInnerBit | node number)
     const float4* surf;
-    const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24 | material type << 28);
+    const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24);
                              // spheres (sphere index, 0, 0, material | flags << 24).  flags: 1 normals,
                              // 2 texcoords, 4 tangents, 8 mesh has a pose
     const float4* matConst;  // per material 2 rows: (value of tex[0] if constant, bits mask), (value of tex[1]

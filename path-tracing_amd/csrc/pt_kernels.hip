@@ -377,7 +377,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
             const uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
                 | (m.animation >= 0 ? 8u : 0u);
             surfAttr[i] = make_uint4(m.first_vertex + idx[0], m.first_vertex + idx[1], m.first_vertex + idx[2],
-                                     uint32_t(m.material) | (flags << 24) | (uint32_t(d->materials[m.material].type) << 28));
+                                     uint32_t(m.material) | (flags << 24));
         } else {
             const pt_sphere& q = d->spheres[s.owner];
             V3 c = v3(q.center);
@@ -397,7 +397,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
             surf[3 * i + 0] = make_float4(c.x, c.y, c.z, bitsf(kind));
             surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, 0.0f);
             surf[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material) | (uint32_t(d->materials[q.material].type) << 28));
+            surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material));
         }
     }
 

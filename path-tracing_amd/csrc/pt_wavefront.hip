@@ -87,7 +87,7 @@ constexpr uint32_t kCtrStride = 32;
 constexpr uint32_t kCtrDone = kShards;
 constexpr uint32_t kCtrShadow = kShards + 1;
 constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // entries in the retry list
-constexpr uint32_t kCtrTiming = 3 * kShards + 2; // debug builds only
+[[maybe_unused]] constexpr uint32_t kCtrTiming = 3 * kShards + 2; // debug builds only
 constexpr uint32_t kCtrWords = (3 * kShards + 8) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
@@ -129,57 +129,6 @@ PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bo
     const uint64_t below = (1ull << lane) - 1ull;
     posA = baseA + uint32_t(__popcll(maskA & below));
     posB = baseB + uint32_t(__popcll(maskB & below));
-}
-
-// Order the slots of a block by what their lanes are going to do, so that the lanes of one
-// wave mostly take the same branches: returns, for this thread, the index (within the block's
-// window of slots) of the slot it handles.  A counting sort over kClasses classes with wave
-// ballots; stable within a class.
-constexpr uint32_t kClasses = 8;
-template <uint32_t WAVES>
-PT_DEV uint32_t blockSortByClass(uint32_t cls, uint32_t* counts /* WAVES * kClasses words */,
-                                 uint16_t* perm /* WAVES * 64 entries */)
-{
-    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
-    const uint64_t below = (1ull << lane) - 1ull;
-    uint32_t rank = 0;
-    // counts[c * WAVES + w]: lanes of class c in wave w
-    for (uint32_t c = 0; c < kClasses; c++) {
-        const uint64_t m = __builtin_amdgcn_ballot_w64(cls == c);
-        if (cls == c)
-            rank = uint32_t(__popcll(m & below));
-        if (lane == c)
-            counts[c * WAVES + wave] = uint32_t(__popcll(m));
-    }
-    __syncthreads();
-    // exclusive prefix sum over the table, by the first wave: each lane sums its own entries,
-    // a scan over the lanes gives where they start
-    if (wave == 0) {
-        constexpr uint32_t kEntries = kClasses * WAVES, kPerLane = (kEntries + 63u) / 64u;
-        uint32_t v[kPerLane], sum = 0;
-        for (uint32_t k = 0; k < kPerLane; k++) {
-            const uint32_t i = lane * kPerLane + k;
-            v[k] = i < kEntries ? counts[i] : 0u;
-            sum += v[k];
-        }
-        uint32_t incl = sum;
-        for (uint32_t d = 1; d < 64u; d <<= 1) {
-            const uint32_t up = uint32_t(__shfl_up(int(incl), d));
-            if (lane >= d)
-                incl += up;
-        }
-        uint32_t run = incl - sum;
-        for (uint32_t k = 0; k < kPerLane; k++) {
-            const uint32_t i = lane * kPerLane + k;
-            if (i < kEntries)
-                counts[i] = run;
-            run += v[k];
-        }
-    }
-    __syncthreads();
-    perm[counts[cls * WAVES + wave] + rank] = uint16_t(threadIdx.x);
-    __syncthreads();
-    return perm[threadIdx.x];
 }
 
 // A shadow ray has found its closest hit: if that is the chosen light, add the prepared
@@ -687,34 +636,12 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) shadeKernel(DevScene sc, Pool 
                                                               float* __restrict__ samples, uint32_t shadowCap)
 {
     __shared__ uint32_t lds[2 * (kShadeWaves + 1)];
-    __shared__ uint32_t sortCounts[kShadeWaves * kClasses];
-    __shared__ uint16_t sortPerm[kShadeBlock];
     const PathParams pp = a.pp;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         counters[kCtrRetry * kCtrStride] = 0; // the retry list of this iteration has been worked off
     PT_T_DECL();
-    // The block owns a window of kShadeBlock slots (the grid covers the slots exactly).  Which
-    // thread takes which slot of the window is decided by what the slot needs: a new path
-    // (free, or its ray left the scene), or the material of the surface that was hit.
-    uint32_t slot;
-    {
-        const uint32_t mine = blockIdx.x * kShadeBlock + threadIdx.x;
-        const uint32_t st = (fbits(pool.d_s[mine].w) >> 16) & 3u;
-        uint32_t cls = 0;
-        if (st == kDone) {
-            cls = kClasses - 1;
-        } else if (st == kActive) {
-            const uint32_t sid = pool.hit[mine].x;
-            if (sid != PT_NO_HIT)
-                cls = min(1u + (sc.surfAttr[sid & 0x7FFFFFFFu].w >> 28), kClasses - 2u);
-        }
-#ifdef PT_SHADE_SORT
-        slot = blockIdx.x * kShadeBlock + blockSortByClass<kShadeWaves>(cls, sortCounts, sortPerm);
-#else
-        slot = mine;
-#endif
-        PT_T(0);
-    }
+    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; // the grid covers the slots exactly
+    PT_T(0);
     // the whole record of the slot, whatever its state: one round trip to memory
     float4 d_s = pool.d_s[slot];
     float4 o_t = pool.o_t[slot];
