@@ -976,10 +976,8 @@ void launchTrace(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t 
     const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
     const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
     // scenes in memory: nearer child first, then the few rays that leaves open in storage order
-    static const bool referenceOrder = [] {
-        const char* v = std::getenv("PT_TRAVERSAL");
-        return v && std::string(v) == "reference";
-    }();
+    const char* traversal = std::getenv("PT_TRAVERSAL");
+    const bool referenceOrder = traversal && std::strcmp(traversal, "reference") == 0;
     const bool ordered = !LDS && !referenceOrder;
     sc->kt.begin(KernelTimes::kTrace, stream);
     if (ordered) {
