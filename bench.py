@@ -151,6 +151,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU machine: PT_BENCH_REHEARSAL=1 puts every rank on GPU 0 and exchanges over gloo
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -162,7 +166,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     scene, cam, label, default_sqrt, extra = workload(args.workload)
     sqrt_spp = args.sqrt_spp or default_sqrt
@@ -201,13 +208,16 @@ def main():
             # this rank's share (its own batch of samples, or its tiles), then one RCCL sum-reduce to rank 0
             if mode == "tiles":
                 out.zero_()
-            for p in shard.shard_params(params, mode, world, rank, tile=256):
+            for p in shard.shard_params(params, mode, world, rank, tile=512):
                 render(p, out)
         if timed:
             e1.record(stream)
             events.append((e0, e1))
         if world > 1 and not frames:
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            if rehearsal:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM)  # gloo has no reduce on device tensors
+            else:
+                dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0 and mode == "batches":
                 out.div_(float(spp * world))
 
@@ -282,7 +292,7 @@ def main():
                        "samples_per_step": total_samples / args.steps,
                        "sharding": "single GPU" if world == 1 else
                        {"batches": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp,
-                        "tiles": "256x256 tiles interleaved over GPUs, RCCL sum-reduce to rank 0",
+                        "tiles": "512x512 tiles interleaved over GPUs, RCCL sum-reduce to rank 0",
                         "frames": "frames round robin over GPUs, no exchange"}[mode]},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
