@@ -311,6 +311,22 @@ typedef struct pt_kernel_time {
 int pt_scene_profile(pt_scene* scene, int enable);
 int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, int* count);
 
+/* ----------------------------------------------------------- output stage -- */
+
+/* What the reference does with the finished image before it writes image.ppm
+ * (reference src/15/pathtracer.cpp:225): to8Bit (src/15/color.hpp:84-98: the
+ * sRGB transfer of color.hpp:36-39, clamp and round of color.hpp:66-70) and
+ * the bottom-up to top-down row order of saveImageAsPPM (src/15/imgsave.hpp:
+ * 29-33); optionally preceded by uniformRationalQuantization (color.hpp:71-82;
+ * enabled by urq_max_val > 0).  in: width * height * 3 floats, row 0 = bottom
+ * (what pt_render writes); out: width * height * 3 bytes, row 0 = top if
+ * flip_rows != 0 (the payload of the PPM file), else in the order of the input.
+ * The _device form reads and writes memory of GPU `device` on the given stream. */
+int pt_image_to_8bit_device(int device, const float* d_rgb, int width, int height, float urq_max_val,
+                            float urq_brightness, int flip_rows, unsigned char* d_out, void* hip_stream);
+int pt_image_to_8bit(int device, const float* rgb, int width, int height, float urq_max_val, float urq_brightness,
+                     int flip_rows, unsigned char* out);
+
 /* ------------------------------------------------------- host-side helpers -- */
 
 /* Build the acceleration structure over [t0, t1] exactly as

@@ -781,6 +781,24 @@ int ref_kat_envmap(ref_scene* s, uint64_t n, const float* dir3, float* out3)
     return 0;
 }
 
+// The reference's output stage on a float image (row 0 = bottom): uniformRationalQuantization if
+// urq_max > 0, to8Bit, and the row order in which saveImageAsPPM writes the bytes if flip != 0.
+int ref_image_to_8bit(const float* rgb, int width, int height, float urq_max, float urq_brightness, int flip,
+                      unsigned char* out)
+{
+    std::vector<vec3> img(size_t(width) * height);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = vec3(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2]);
+    if (urq_max > 0.0f)
+        uniformRationalQuantization(img, urq_max, urq_brightness);
+    std::vector<unsigned char> bytes = to8Bit(img);
+    for (int y = 0; y < height; y++) {
+        int line = flip ? height - 1 - y : y;
+        std::memcpy(out + size_t(y) * width * 3, bytes.data() + size_t(line) * width * 3, size_t(width) * 3);
+    }
+    return 0;
+}
+
 // Animation::at(t) of a POD animation -> POD transform (slerp included)
 int ref_kat_animation(const pt_animation* a, float t, pt_transform* out)
 {

@@ -6,5 +6,6 @@ include/pt_amd.h); this package is its Python face for tests and benchmarks.
 from . import abi  # noqa: F401
 from .api import (  # noqa: F401
     DeviceScene, FlatScene, LoadedScene, PtError, device_count, lib, load_camera, make_animation, make_camera,
-    make_params, make_transform, identity_transform, n_samples, save_camera, HIT_DTYPE, NODE_DTYPE, LIB_PATH,
+    make_params, make_transform, identity_transform, n_samples, save_camera, image_to_8bit, image_to_8bit_device,
+    HIT_DTYPE, NODE_DTYPE, LIB_PATH,
 )

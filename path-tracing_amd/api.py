@@ -46,6 +46,9 @@ def lib():
         L.pt_last_kernel_ms.argtypes = [C.c_void_p]
         L.pt_scene_profile.argtypes = [C.c_void_p, C.c_int]
         L.pt_scene_kernel_times.argtypes = [C.c_void_p, C.POINTER(abi.pt_kernel_time), C.c_int, C.POINTER(C.c_int)]
+        L.pt_image_to_8bit.argtypes = [C.c_int, _fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.pt_image_to_8bit_device.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                              C.c_void_p, C.c_void_p]
         L.pt_scene_destroy.argtypes = [C.c_void_p]
         L.pt_scene_destroy.restype = None
         L.pt_scene_desc_free.argtypes = [C.c_void_p]
@@ -141,6 +144,24 @@ def make_params(width, height, sqrt_spp, seed=42, t0=0.0, t1=0.0, tile=None, sam
     p.max_path_segments = max_path_segments
     p.rr_start_segment = rr_start_segment
     return p
+
+
+def image_to_8bit(img, device=0, urq=None, flip_rows=True):
+    """The reference's output stage on the GPU: (H, W, 3) float32 with row 0 = bottom -> (H, W, 3) uint8, rows in
+    file order if flip_rows.  urq = (max_val, brightness) applies uniformRationalQuantization first."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[0], img.shape[1]
+    out = np.empty((h, w, 3), np.uint8)
+    mx, br = urq if urq else (0.0, 1.0)
+    _check(lib().pt_image_to_8bit(device, _f(img), w, h, mx, br, 1 if flip_rows else 0, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def image_to_8bit_device(d_rgb_ptr, width, height, d_out_ptr, device=0, urq=None, flip_rows=True, stream_ptr=None):
+    """Same, on device memory (raw pointers) and asynchronous on the given stream."""
+    mx, br = urq if urq else (0.0, 1.0)
+    _check(lib().pt_image_to_8bit_device(device, C.c_void_p(d_rgb_ptr), width, height, mx, br, 1 if flip_rows else 0,
+                                         C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
 
 
 def n_samples(p):

@@ -629,6 +629,107 @@ int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, in
     return PT_OK;
 }
 
+// ---------------------------------------------------------------- output stage
+namespace {
+
+// reference src/15/color.hpp:36-39
+PT_DEV float linearToNonlinear(float x)
+{
+    return x <= 0.0031308f ? (x * 12.92f) : (1.055f * ptm::powf(x, 1.0f / 2.4f) - 0.055f);
+}
+
+// reference src/15/color.hpp:66-70
+PT_DEV unsigned char floatToByte(float x)
+{
+    x = (x < 0.0f ? 0.0f : x > 1.0f ? 1.0f : x);
+    return (unsigned char)(::roundf(x * 255.0f));
+}
+
+// reference src/15/color.hpp:5-34,71-82
+PT_DEV V3 rationalQuantization(V3 rgb, float maxVal, float brightness)
+{
+    V3 xyz = 100.0f * v3(0.412453f * rgb.x + 0.357580f * rgb.y + 0.180423f * rgb.z,
+                         0.212671f * rgb.x + 0.715160f * rgb.y + 0.072169f * rgb.z,
+                         0.019334f * rgb.x + 0.119193f * rgb.y + 0.950227f * rgb.z);
+    float oldY = xyz.y;
+    float newY = brightness * oldY / ((brightness - 1.0f) * oldY + maxVal);
+    float target = 100.0f * newY;
+    V3 adj = v3(0.0f);
+    if (!(xyz.y <= 0.0f)) {
+        float sum = xyz.x + xyz.y + xyz.z;
+        if (!(sum <= 0.0f)) {
+            float x = xyz.x / sum;
+            float y = xyz.y / sum;
+            float r = target / y;
+            adj = v3(r * x, target, r * (1.0f - x - y));
+        }
+    }
+    return 0.01f * v3(+3.240479f * adj.x - 1.537150f * adj.y - 0.498535f * adj.z,
+                      -0.969256f * adj.x + 1.875991f * adj.y + 0.041556f * adj.z,
+                      +0.055648f * adj.x - 0.204023f * adj.y + 1.057311f * adj.z);
+}
+
+__global__ void __launch_bounds__(256) to8BitKernel(const float* __restrict__ rgb, int width, int height, float urqMax,
+                                                    float urqBrightness, int flip, unsigned char* __restrict__ out)
+{
+    const size_t i = size_t(blockIdx.x) * 256u + threadIdx.x;
+    if (i >= size_t(width) * size_t(height))
+        return;
+    V3 c = v3(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2]);
+    if (urqMax > 0.0f)
+        c = rationalQuantization(c, urqMax, urqBrightness);
+    const size_t y = i / size_t(width), x = i % size_t(width);
+    const size_t o = ((flip ? size_t(height) - 1 - y : y) * size_t(width) + x) * 3;
+    out[o + 0] = floatToByte(linearToNonlinear(c.x));
+    out[o + 1] = floatToByte(linearToNonlinear(c.y));
+    out[o + 2] = floatToByte(linearToNonlinear(c.z));
+}
+
+} // namespace
+
+int pt_image_to_8bit_device(int device, const float* d_rgb, int width, int height, float urq_max_val,
+                            float urq_brightness, int flip_rows, unsigned char* d_out, void* hip_stream)
+{
+    if (!d_rgb || !d_out || width <= 0 || height <= 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_image_to_8bit_device: null buffer or empty image");
+    DeviceGuard g(device);
+    if (!g.ok)
+        return fail(PT_ERR_DEVICE, "cannot select GPU " + std::to_string(device));
+    const size_t n = size_t(width) * size_t(height);
+    hipLaunchKernelGGL(to8BitKernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       d_rgb, width, height, urq_max_val, urq_brightness, flip_rows, d_out);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_image_to_8bit(int device, const float* rgb, int width, int height, float urq_max_val, float urq_brightness,
+                     int flip_rows, unsigned char* out)
+{
+    if (!rgb || !out || width <= 0 || height <= 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_image_to_8bit: null buffer or empty image");
+    DeviceGuard g(device);
+    if (!g.ok)
+        return fail(PT_ERR_DEVICE, "cannot select GPU " + std::to_string(device));
+    const size_t n = size_t(width) * size_t(height);
+    float* dIn = nullptr;
+    unsigned char* dOut = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dIn), n * 3 * sizeof(float)));
+    if (hipMalloc(reinterpret_cast<void**>(&dOut), n * 3) != hipSuccess) {
+        (void)hipFree(dIn);
+        return fail(PT_ERR_DEVICE, "out of device memory");
+    }
+    int rc = PT_OK;
+    if (hipMemcpy(dIn, rgb, n * 3 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PT_ERR_DEVICE, "copy to the device failed");
+    if (rc == PT_OK)
+        rc = pt_image_to_8bit_device(device, dIn, width, height, urq_max_val, urq_brightness, flip_rows, dOut, nullptr);
+    if (rc == PT_OK && hipMemcpy(out, dOut, n * 3, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PT_ERR_DEVICE, "copy from the device failed");
+    (void)hipFree(dIn);
+    (void)hipFree(dOut);
+    return rc;
+}
+
 int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                       float* out_rgb_per_sample)
 {

@@ -482,6 +482,24 @@ inline std::vector<vec3> render(const Scene& scene, const Camera& camera, int wi
     pt_scene_destroy(dev);
     return img;
 }
+
+// Drop-in for to8Bit(img) (reference src/15/color.hpp:84-98, used at src/15/pathtracer.cpp:225):
+// same bytes in the same (image) row order, computed on the GPU; saveImageAsPPM then writes
+// them as before.  Empty on failure.
+inline std::vector<unsigned char> to8Bit(const std::vector<vec3>& img, int width, int height, std::string* err = nullptr,
+                                         int device = 0)
+{
+    std::vector<unsigned char> bytes(img.size() * 3);
+    static_assert(sizeof(vec3) == 3 * sizeof(float));
+    if (img.size() != size_t(width) * size_t(height)
+        || pt_image_to_8bit(device, reinterpret_cast<const float*>(img.data()), width, height, 0.0f, 1.0f, 0, bytes.data())
+            != PT_OK) {
+        if (err)
+            *err = img.size() != size_t(width) * size_t(height) ? "image size does not match" : pt_last_error();
+        bytes.clear();
+    }
+    return bytes;
+}
 #endif
 
 } // namespace ptamd

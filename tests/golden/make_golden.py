@@ -127,6 +127,12 @@ def gen_mesh_vectors(R):
     rs.close()
 
 
+def gen_output_stage(R):
+    img = scenes.output_stage_image()
+    np.savez(out("output_stage.npz"), plain=R.image_to_8bit(img), urq=R.image_to_8bit(img, urq=(2.5, 20.0)),
+             unflipped=R.image_to_8bit(img, flip_rows=False))
+
+
 def gen_kat(R):
     rng = np.random.default_rng(7)
     n = 256
@@ -164,7 +170,7 @@ def main():
     args = ap.parse_args()
     R = refbind.Reference()
     steps = {"cornell": gen_cornell, "cornell_vectors": gen_cornell_vectors, "families": gen_family_vectors,
-             "mesh": gen_mesh_vectors, "kat": gen_kat}
+             "mesh": gen_mesh_vectors, "output": gen_output_stage, "kat": gen_kat}
     for name, fn in steps.items():
         if args.only and args.only != name:
             continue

@@ -63,6 +63,10 @@ class Reference:
                                              C.byref(animation) if animation is not None else None, C.byref(cam)))
         return cam
 
+    def image_to_8bit(self, img, urq=None, flip_rows=True):
+        """The reference's to8Bit (after uniformRationalQuantization if urq) in saveImageAsPPM's row order."""
+        return _to_8bit(self.lib.ref_image_to_8bit, self._check, img, urq, flip_rows)
+
     def lookat(self, eye, center, up=(0.0, 1.0, 0.0)):
         T = abi.pt_transform()
         e = np.asarray(eye, np.float32)
@@ -230,6 +234,15 @@ def make_params(width, height, sqrt_spp, seed=42, t0=0.0, t1=0.0, tile=None, sam
     return p
 
 
+def _to_8bit(fn, check, img, urq, flip, *extra):
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[0], img.shape[1]
+    out = np.empty((h, w, 3), np.uint8)
+    mx, br = urq if urq else (0.0, 1.0)
+    check(fn(_f(img), w, h, C.c_float(mx), C.c_float(br), 1 if flip else 0, *extra, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 class Oracle:
     """The CPU restatement (oracle/libpt_oracle.so). math_mode 0 = C library, 1 = portable."""
 
@@ -294,6 +307,9 @@ class Oracle:
                                                        C.c_uint32(stack_limit), out, stats))
         return hits_to_numpy(out), {"box_tests": int(stats[0]), "fell_back": int(stats[1]),
                                     "deepest": int(stats[2]), "depth_hist": [int(x) for x in stats[3:67]]}
+
+    def image_to_8bit(self, img, urq=None, flip_rows=True, math_mode=1):
+        return _to_8bit(self.lib.oracle_image_to_8bit, self._check, img, urq, flip_rows, math_mode)
 
     def kat_warp(self, which, u0, u1, param=None, math_mode=0):
         u0 = np.ascontiguousarray(u0, np.float32)

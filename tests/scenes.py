@@ -304,3 +304,13 @@ def big_mesh_scene(n, seed=1):
     cam = pt.make_camera(math.tan(math.radians(25.0)), math.tan(math.radians(25.0)) * 16 / 9, 1.0, 0.0,
                          lookat_animation((0.0, 45.0, 140.0), (0.0, 0.0, 0.0)))
     return s, cam
+
+
+def output_stage_image():
+    """Seeded high-dynamic-range test image: values below 0, around the sRGB knee, above 1."""
+    rng = np.random.default_rng(99)
+    img = np.exp(rng.normal(-1.5, 2.0, (48, 64, 3))).astype(np.float32)
+    img[0, :8] = -0.25
+    img[1, :8] = np.linspace(0.0, 0.0062616, 24, dtype=np.float32).reshape(8, 3)
+    img[2, :8] = 1.0
+    return img

@@ -257,3 +257,19 @@ def test_walk_orders_agree_on_a_mesh(oracle):
     assert same_bits(fast, slow)
     d = s.desc()
     assert same_bits(fast, oracle.render(C.byref(d), cam, p, math_mode=1))
+
+
+def test_output_stage(cornell, golden_dir, oracle):
+    """Device to8Bit + row flip (+ uniformRationalQuantization): byte-exact against the oracle, and against the
+    reference-generated bytes up to the stated rate of one-off differences from the C library's pow."""
+    img = scenes.output_stage_image()
+    g = np.load(os.path.join(golden_dir, "output_stage.npz"))
+    for key, kw in (("plain", {}), ("urq", {"urq": (2.5, 20.0)}), ("unflipped", {"flip_rows": False})):
+        got = pt.image_to_8bit(img, **kw)
+        assert np.array_equal(got, oracle.image_to_8bit(img, math_mode=1, **kw)), key
+        diff = np.abs(got.astype(np.int32) - g[key].astype(np.int32))
+        assert diff.max() <= 1 and np.mean(diff != 0) <= 1e-3, key
+    # a rendered image, as the reference's main does after the pixel loop (src/15/pathtracer.cpp:225)
+    scene, cam, dev = cornell
+    rgb = dev.render(cam, pt.make_params(96, 64, 4))
+    assert np.array_equal(pt.image_to_8bit(rgb), oracle.image_to_8bit(rgb, math_mode=1))
