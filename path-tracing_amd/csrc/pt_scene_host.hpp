@@ -60,17 +60,14 @@ int upload(const T* host, size_t count, T** dev, std::vector<void*>& owned)
 
 // Work areas of the wavefront renderer, allocated on first use and kept.
 struct WavefrontBuffers {
-    void* pool = nullptr;       // path-state arrays of the lanes
+    void* pool = nullptr;       // path-state arrays, queues, retry list
     size_t poolCapacity = 0;    // bytes
     float* samples = nullptr;   // per-sample radiance of one batch
     uint64_t sampleCapacity = 0; // in samples (3 floats each)
     float* accum = nullptr;     // running per-pixel sums across batches
     uint64_t accumCapacity = 0; // in pixels
-    uint32_t* counters = nullptr;     // one block of counters per lane
+    uint32_t* counters = nullptr;
     uint32_t* hostCounters = nullptr; // pinned
-    uint32_t nLanes = 0;
-    hipStream_t shadeStream = nullptr; // the shading kernels of the two lanes run here, the tracing kernels on the caller's stream
-    hipEvent_t traced[2] = {nullptr, nullptr}, shaded[2] = {nullptr, nullptr};
 };
 
 // Per-kernel device time of the wavefront renderer, measured with pairs of events on the

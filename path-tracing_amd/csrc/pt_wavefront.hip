@@ -903,12 +903,10 @@ Pool carvePool(void* base, uint32_t n)
     return p;
 }
 
-constexpr uint32_t kMaxLanes = 2;
-
-int ensureBuffers(pt_scene* sc, uint32_t slotsPerLane, uint32_t nLanes, uint64_t nSamples, uint64_t npix)
+int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npix)
 {
     WavefrontBuffers& w = sc->wf;
-    const size_t needPool = poolBytes(slotsPerLane) * nLanes;
+    const size_t needPool = poolBytes(nSlots);
     if (w.poolCapacity < needPool) {
         if (w.pool)
             (void)hipFree(w.pool);
@@ -934,43 +932,24 @@ int ensureBuffers(pt_scene* sc, uint32_t slotsPerLane, uint32_t nLanes, uint64_t
         w.accumCapacity = npix;
     }
     if (!w.counters)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), kMaxLanes * kCtrWords * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), kCtrWords * sizeof(uint32_t)));
     if (!w.hostCounters)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), kMaxLanes * kCtrWords * sizeof(uint32_t)));
-    if (nLanes > 1 && !w.shadeStream) {
-        HIP_TRY(hipStreamCreateWithFlags(&w.shadeStream, hipStreamNonBlocking));
-        for (uint32_t l = 0; l < kMaxLanes; l++) {
-            HIP_TRY(hipEventCreateWithFlags(&w.traced[l], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&w.shaded[l], hipEventDisableTiming));
-        }
-    }
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), kCtrWords * sizeof(uint32_t)));
     return PT_OK;
 }
 
 // node + surface tables up to this size are traced from LDS
 constexpr size_t kLdsGeoLimit = 16 * 1024;
 
-// A lane: a pool of path slots working through its own share of a batch's samples.  Two lanes
-// run side by side so that the tracing kernel of one (bound by vector instruction issue)
-// overlaps the shading kernel of the other (bound by memory latency).
-struct Lane {
-    Pool pool;
-    Batch b;
-    uint32_t* counters;
-    uint32_t* hostCounters;
-    float* samples; // the lane's part of the sample buffer
-    bool done;
-};
-
-// the tracing kernel of one iteration of a lane
+// the tracing step of one iteration
 template <bool DYN, bool LDS>
-void launchTrace(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t stream, int parity)
+void launchTrace(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity)
 {
-    const Pool& pool = ln.pool;
+    WavefrontBuffers& w = sc->wf;
     const dim3 block(256);
     const uint32_t run = 64u * kItemsPerLane;
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
-    // tracing: whole blocks of slot waves, then whole blocks of shadow-queue waves
+    // whole blocks of slot waves, then whole blocks of shadow-queue waves
     const uint32_t slotWaves = ((pool.nSlots + run - 1) / run + 3u) / 4u * 4u;
     const uint32_t shadowWaves = (shadowCap * kShards / run + 3u) / 4u * 4u;
     const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
@@ -981,45 +960,37 @@ void launchTrace(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t 
     const bool ordered = !LDS && !referenceOrder;
     sc->kt.begin(KernelTimes::kTrace, stream);
     if (ordered) {
-        hipLaunchKernelGGL((traceOrderedKernel<DYN>), gridTrace, block, 0, stream, sc->dev, pool, ln.counters, parity,
-                           ln.samples, shadowCap, slotWaves);
+        hipLaunchKernelGGL((traceOrderedKernel<DYN>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity,
+                           w.samples, shadowCap, slotWaves);
         const uint32_t retryBlocks = std::min<uint32_t>(2048u, (pool.nSlots + shadowCap * kShards + 255u) / 256u);
-        hipLaunchKernelGGL((traceRetryKernel<DYN>), dim3(retryBlocks), block, 0, stream, sc->dev, pool, ln.counters,
-                           ln.samples);
+        hipLaunchKernelGGL((traceRetryKernel<DYN>), dim3(retryBlocks), block, 0, stream, sc->dev, pool, w.counters,
+                           w.samples);
     } else {
-        hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, ln.counters, parity,
-                           ln.samples, shadowCap, slotWaves);
+        hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
+                           w.samples, shadowCap, slotWaves);
     }
     sc->kt.end(stream);
 }
 
-void launchShade(pt_scene* sc, const RenderArgs& a, const Lane& ln, hipStream_t stream, int parity)
+void launchTraceFor(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity, bool dyn, bool lds)
 {
-    const Pool& pool = ln.pool;
-    sc->kt.begin(KernelTimes::kShade, stream);
-    hipLaunchKernelGGL(shadeKernel, dim3(pool.nSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, sc->dev, pool, a, ln.b, ln.counters,
-                       parity, ln.samples, shadowCapOf(pool.nSlots));
-    sc->kt.end(stream);
+    if (dyn && lds)
+        launchTrace<true, true>(sc, pool, stream, parity);
+    else if (dyn)
+        launchTrace<true, false>(sc, pool, stream, parity);
+    else if (lds)
+        launchTrace<false, true>(sc, pool, stream, parity);
+    else
+        launchTrace<false, false>(sc, pool, stream, parity);
 }
 
-// Run the lanes until every path of their shares has finished.  Per iteration and lane:
-// generate + trace on the caller's stream, shade on the shading stream, chained by events
-// (shade after its trace, the next trace after that shade); with one lane everything is on
-// the caller's stream.
-int runLanes(pt_scene* sc, const RenderArgs& a, Lane* lanes, uint32_t nLanes, hipStream_t stream)
+// Run one batch of samples [b.sFirst, b.sFirst + b.nS) of every pixel of the tile into the sample buffer.
+int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream)
 {
     WavefrontBuffers& w = sc->wf;
-    const bool two = nLanes > 1;
-    hipStream_t sShade = two ? w.shadeStream : stream;
-    HIP_TRY(hipMemsetAsync(w.counters, 0, kMaxLanes * kCtrWords * sizeof(uint32_t), stream));
-    uint64_t maxIters = 0;
-    for (uint32_t l = 0; l < nLanes; l++) {
-        const Pool& pool = lanes[l].pool;
-        HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
-        maxIters = std::max<uint64_t>(maxIters, (uint64_t(lanes[l].b.totalIds) / pool.nSlots + 2)
-                                                        * uint64_t(a.pp.maxSegments + 2) + 64);
-        lanes[l].done = false;
-    }
+    HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
+    const uint64_t maxIters = (uint64_t(b.totalIds) / pool.nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const int checkEvery = 16;
     const bool dyn = sc->hasDynamic;
     const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
@@ -1028,38 +999,19 @@ int runLanes(pt_scene* sc, const RenderArgs& a, Lane* lanes, uint32_t nLanes, hi
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
             const int parity = int(iter & 1);
-            for (uint32_t l = 0; l < nLanes; l++) {
-                const Lane& ln = lanes[l];
-                if (ln.done)
-                    continue;
-                if (two && iter > 0)
-                    HIP_TRY(hipStreamWaitEvent(stream, w.shaded[l], 0));
-                if (dyn && lds)
-                    launchTrace<true, true>(sc, a, ln, stream, parity);
-                else if (dyn)
-                    launchTrace<true, false>(sc, a, ln, stream, parity);
-                else if (lds)
-                    launchTrace<false, true>(sc, a, ln, stream, parity);
-                else
-                    launchTrace<false, false>(sc, a, ln, stream, parity);
-                if (two) {
-                    HIP_TRY(hipEventRecord(w.traced[l], stream));
-                    HIP_TRY(hipStreamWaitEvent(sShade, w.traced[l], 0));
-                }
-                launchShade(sc, a, ln, sShade, parity);
-                if (two)
-                    HIP_TRY(hipEventRecord(w.shaded[l], sShade));
-            }
+            launchTraceFor(sc, pool, stream, parity, dyn, lds);
+            sc->kt.begin(KernelTimes::kShade, stream);
+            hipLaunchKernelGGL(shadeKernel, dim3(pool.nSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, sc->dev, pool, a,
+                               b, w.counters, parity, w.samples, shadowCapOf(pool.nSlots));
+            sc->kt.end(stream);
         }
         HIP_TRY(hipGetLastError());
-        // the shading stream is the last to finish an iteration
-        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kMaxLanes * kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                               sShade));
-        HIP_TRY(hipStreamSynchronize(sShade));
+        HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         sc->kt.collect();
 #ifdef PT_SHADE_TIMING
         if (std::getenv("PT_SHADE_TIMING_PRINT")) {
-            static const char* names[12] = { "sort", "state", "makeHit", "scatter+Le", "lightsPdf1", "lightSample", "lightsPdf2",
+            static const char* names[12] = { "-", "state", "makeHit", "scatter+Le", "lightsPdf1", "lightSample", "lightsPdf2",
                                              "toDirection+emission", "rr+finish", "reserve", "generate", "stores" };
             double tot = 0;
             for (int k = 0; k < 12; k++)
@@ -1067,33 +1019,16 @@ int runLanes(pt_scene* sc, const RenderArgs& a, Lane* lanes, uint32_t nLanes, hi
             fprintf(stderr, "shade sections (%% of wave cycles, iter %llu):", (unsigned long long)iter);
             for (int k = 0; k < 12; k++)
                 fprintf(stderr, " %s=%.1f", names[k], 100.0 * w.hostCounters[(kCtrTiming + k / 4) * kCtrStride + 8 + (k % 4) * 2] / tot);
-            fprintf(stderr, "  total=%.3g cycles/wave-launch\n", tot * 256.0 / (double(iter) * (lanes[0].pool.nSlots / 64)));
+            fprintf(stderr, "\n");
         }
 #endif
-        bool all = true;
-        for (uint32_t l = 0; l < nLanes; l++) {
-            if (lanes[l].hostCounters[kCtrDone * kCtrStride] >= lanes[l].pool.nSlots)
-                lanes[l].done = true;
-            all = all && lanes[l].done;
-        }
-        if (all)
+        if (w.hostCounters[kCtrDone * kCtrStride] >= pool.nSlots)
             break;
         if (iter > maxIters)
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
     // the last paths may have queued shadow rays in the very last shading launch: trace those
-    // (the host has waited for both streams, so the caller's stream can take over)
-    for (uint32_t l = 0; l < nLanes; l++) {
-        const int parity = int(iter & 1);
-        if (dyn && lds)
-            launchTrace<true, true>(sc, a, lanes[l], stream, parity);
-        else if (dyn)
-            launchTrace<true, false>(sc, a, lanes[l], stream, parity);
-        else if (lds)
-            launchTrace<false, true>(sc, a, lanes[l], stream, parity);
-        else
-            launchTrace<false, false>(sc, a, lanes[l], stream, parity);
-    }
+    launchTraceFor(sc, pool, stream, int(iter & 1), dyn, lds);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -1115,48 +1050,29 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     perBatch = std::min<uint64_t>(perBatch, nsTotal);
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    // two lanes share the slots when a batch has at least two samples per pixel
-    const uint32_t nLanes = (perBatch >= 2 && envU64("PT_WAVEFRONT_LANES", 1) >= 2) ? 2u : 1u;
-    uint64_t laneSlots = envU64("PT_WAVEFRONT_SLOTS", 1u << 22) / nLanes;
-    laneSlots = std::min<uint64_t>(laneSlots, idsPerSample * ((perBatch + nLanes - 1) / nLanes));
-    laneSlots = std::max<uint64_t>((laneSlots + kShadeBlock - 1) / kShadeBlock * kShadeBlock, kShadeBlock); // whole shading blocks
-    int rc = ensureBuffers(sc, uint32_t(laneSlots), nLanes, npix * perBatch, npix);
+    uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 22), idsPerSample * perBatch);
+    nSlots = std::max<uint64_t>((nSlots + kShadeBlock - 1) / kShadeBlock * kShadeBlock, kShadeBlock); // whole shading blocks
+    int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
     if (rc != PT_OK)
         return rc;
     WavefrontBuffers& w = sc->wf;
+    const Pool pool = carvePool(w.pool, uint32_t(nSlots));
     HIP_TRY(hipEventRecord(sc->evStart, stream));
     for (uint32_t s = 0; s < nsTotal; s += uint32_t(perBatch)) {
-        const uint32_t nS = std::min<uint32_t>(uint32_t(perBatch), nsTotal - s);
-        Lane lanes[kMaxLanes];
-        uint32_t used = 0, sLane = 0;
-        for (uint32_t l = 0; l < nLanes; l++) {
-            const uint32_t share = (nS - sLane + (nLanes - l) - 1) / (nLanes - l);
-            if (share == 0)
-                continue;
-            Lane& ln = lanes[used];
-            ln.pool = carvePool(static_cast<char*>(w.pool) + poolBytes(uint32_t(laneSlots)) * used, uint32_t(laneSlots));
-            ln.b.tilesX = tilesX;
-            ln.b.tilesY = tilesY;
-            ln.b.nS = share;
-            ln.b.sFirst = uint32_t(a.s0) + s + sLane;
-            ln.b.npix = uint32_t(npix);
-            ln.b.totalIds = uint32_t(idsPerSample * share);
-            ln.counters = w.counters + size_t(used) * kCtrWords;
-            ln.hostCounters = w.hostCounters + size_t(used) * kCtrWords;
-            ln.samples = w.samples + 3 * npix * sLane;
-            ln.done = false;
-            sLane += share;
-            used++;
-        }
-        rc = runLanes(sc, a, lanes, used, stream);
+        Batch b;
+        b.tilesX = tilesX;
+        b.tilesY = tilesY;
+        b.nS = std::min<uint32_t>(uint32_t(perBatch), nsTotal - s);
+        b.sFirst = uint32_t(a.s0) + s;
+        b.npix = uint32_t(npix);
+        b.totalIds = uint32_t(idsPerSample * b.nS);
+        rc = runBatch(sc, a, b, pool, stream);
         if (rc != PT_OK)
             return rc;
         if (d_out) {
-            Batch b = lanes[0].b; // the whole batch: its samples lie one lane after the other
-            b.nS = nS;
             sc->kt.begin(KernelTimes::kResolve, stream);
             hipLaunchKernelGGL(resolveKernel, dim3((b.npix + 255u) / 256u), dim3(256), 0, stream, w.samples, w.accum,
-                               d_out, a, b, s == 0 ? 1 : 0, s + nS >= nsTotal ? 1 : 0);
+                               d_out, a, b, s == 0 ? 1 : 0, s + b.nS >= nsTotal ? 1 : 0);
             sc->kt.end(stream);
             HIP_TRY(hipGetLastError());
         }
@@ -1203,14 +1119,6 @@ void ptWavefrontRelease(pt_scene* scene)
         (void)hipFree(w.counters);
     if (w.hostCounters)
         (void)hipHostFree(w.hostCounters);
-    if (w.shadeStream)
-        (void)hipStreamDestroy(w.shadeStream);
-    for (uint32_t l = 0; l < kMaxLanes; l++) {
-        if (w.traced[l])
-            (void)hipEventDestroy(w.traced[l]);
-        if (w.shaded[l])
-            (void)hipEventDestroy(w.shaded[l]);
-    }
     w = WavefrontBuffers();
     scene->kt.release();
 }

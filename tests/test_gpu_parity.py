@@ -273,3 +273,40 @@ def test_output_stage(cornell, golden_dir, oracle):
     scene, cam, dev = cornell
     rgb = dev.render(cam, pt.make_params(96, 64, 4))
     assert np.array_equal(pt.image_to_8bit(rgb), oracle.image_to_8bit(rgb, math_mode=1))
+
+
+def test_edge_cases(cornell, oracle):
+    """Ragged and degenerate inputs: one pixel, sizes that are not multiples of the 8x8 path tiles, one
+    sample, an empty tile and an empty sample range, a scene of a single surface, a scene without lights."""
+    scene, cam, dev = cornell
+    for (w, h, s) in [(1, 1, 1), (1, 1, 3), (33, 17, 1), (7, 9, 2), (130, 3, 1)]:
+        p = pt.make_params(w, h, s)
+        assert same_bits(dev.render_samples(cam, p), oracle.render_samples(scene.ptr, cam, p, math_mode=1)), (w, h, s)
+        assert same_bits(dev.render(cam, p), oracle.render(scene.ptr, cam, p, math_mode=1)), (w, h, s)
+    # nothing to do: the output is left alone
+    out = np.full((16, 16, 3), 7.0, np.float32)
+    dev.render(cam, pt.make_params(16, 16, 2, tile=(5, 5, 5, 9)), out=out)
+    assert np.all(out == 7.0)
+    # bad arguments are errors
+    with pytest.raises(pt.PtError):
+        dev.render(cam, pt.make_params(16, 16, 2, tile=(5, 5, 40, 9)))
+    with pytest.raises(pt.PtError):
+        dev.render(cam, pt.make_params(16, 16, 2, samples=(3, 9)))
+    with pytest.raises(pt.PtError):
+        dev.render(cam, pt.make_params(0, 16, 2))
+    # a single triangle that is its own light, seen from both sides; and a sphere with no light at all
+    one = pt.FlatScene()
+    one.add_mesh(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), np.array([0, 1, 2], np.uint32),
+                 one.material_light((2.0, 3.0, 4.0)), is_light=True)
+    one.build_bvh()
+    dark = pt.FlatScene()
+    dark.add_sphere((0.0, 0.0, 0.0), 1.0, dark.material_lambertian(dark.texture_constant((0.5, 0.5, 0.5))))
+    dark.set_envmap_equirect(dark.texture_constant((1.0, 0.9, 0.8)))
+    dark.build_bvh()
+    for s in (one, dark):
+        for eye in ((0.0, 0.3, 3.0), (0.2, 0.0, -3.0)):
+            c = pt.make_camera(0.5, 0.5, 1.0, 0.0, scenes.lookat_animation(eye, (0.0, 0.0, 0.0)))
+            p = pt.make_params(20, 20, 2)
+            d = s.desc()
+            with pt.DeviceScene(s) as ds:
+                assert same_bits(ds.render_samples(c, p), oracle.render_samples(C.byref(d), c, p, math_mode=1))
