@@ -192,7 +192,7 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #define PT_REFILL_LANES 16
 #endif
 #ifndef PT_WALK_LANES
-#define PT_WALK_LANES 32
+#define PT_WALK_LANES 24
 #endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
@@ -348,13 +348,16 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
 // and a stack of (link, gate) in LDS.  A step at an inner node reads one 64-byte row with
 // the boxes and leaf fields of both children.
 #ifndef PT_STACK_DEPTH
-#define PT_STACK_DEPTH 16
+#define PT_STACK_DEPTH 12
 #endif
 constexpr uint32_t kStackDepth = PT_STACK_DEPTH;
 constexpr float kTieBand = 1.0e-4f;
 
+#ifndef PT_ORDERED_WAVES
+#define PT_ORDERED_WAVES 1
+#endif
 template <bool DYN>
-__global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
+__global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                           float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
 {
     __shared__ uint2 stack[kStackDepth][256];
@@ -391,12 +394,9 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
     Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
     uint32_t link = 0, top = 0;
     bool walkOver = true; // nothing left to visit
-    float gate = 0.0f, cull = kFltMax, otherT = kFltMax, bestGate = 0.0f;
+    float gate = 0.0f, cull = kFltMax, otherT = kFltMax;
     float dropGate = __builtin_huge_valf(); // nearest entry distance of a subtree that found no room on the stack
     HitLite best = noHit();
-    float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    V3 destValue = v3(0.0f);
-    uint32_t dest = 0, destW = 0;
 
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
@@ -415,17 +415,9 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
                         have = true;
                     }
                 } else {
+                    // (what to add on arrival is read when the ray arrives: fewer registers held
+                    // through the walk, more waves in flight)
                     const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
-                    payload = pool.sh_c[itemBase + item];
-                    dest = fbits(sd.w);
-                    if (fbits(payload.w) & kDestIsSample) {
-                        const float* p = samples + 3 * size_t(dest);
-                        destValue = v3(p[0], p[1], p[2]);
-                    } else {
-                        const float4 r = pool.rad_p[dest];
-                        destValue = v3(r.x, r.y, r.z);
-                        destW = fbits(r.w);
-                    }
                     ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
                     have = true;
                 }
@@ -433,7 +425,6 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
                     best = noHit();
                     cull = kFltMax;
                     otherT = kFltMax;
-                    bestGate = 0.0f;
                     dropGate = __builtin_huge_valf();
                     top = 0;
                     // the root
@@ -510,8 +501,7 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
                     if (best.sid != PT_NO_HIT)
                         otherT = fminf(otherT, best.a);
                     best = h;
-                    bestGate = gate;
-                    cull = fmaxf(best.a, bestGate) * (1.0f + kTieBand);
+                    cull = fmaxf(best.a, gate) * (1.0f + kTieBand);
                     if (!(cull < kFltMax))
                         cull = kFltMax;
                 } else {
@@ -554,8 +544,22 @@ __global__ void __launch_bounds__(256) traceOrderedKernel(DevScene sc, Pool pool
             } else if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
-            } else {
-                shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
+            } else if (best.sid != PT_NO_HIT) {
+                const float4 payload = pool.sh_c[itemBase + item];
+                if (best.sid == (fbits(payload.w) & kLightMask)) {
+                    const uint32_t dest = fbits(pool.sh_d[itemBase + item].w);
+                    V3 destValue;
+                    uint32_t destW = 0;
+                    if (fbits(payload.w) & kDestIsSample) {
+                        const float* p = samples + 3 * size_t(dest);
+                        destValue = v3(p[0], p[1], p[2]);
+                    } else {
+                        const float4 r = pool.rad_p[dest];
+                        destValue = v3(r.x, r.y, r.z);
+                        destW = fbits(r.w);
+                    }
+                    shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
+                }
             }
         }
     }
