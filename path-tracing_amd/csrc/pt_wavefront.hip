@@ -635,7 +635,10 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
 constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK; // threads per block of the shading kernel
 constexpr uint32_t kShadeWaves = kShadeBlock / 64u;
 
-__global__ void __launch_bounds__(PT_SHADE_BLOCK) shadeKernel(DevScene sc, Pool pool, RenderArgs a, Batch b,
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
+__global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(DevScene sc, Pool pool, RenderArgs a, Batch b,
                                                               uint32_t* __restrict__ counters, int parity,
                                                               float* __restrict__ samples, uint32_t shadowCap)
 {

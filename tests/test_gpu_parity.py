@@ -310,3 +310,21 @@ def test_edge_cases(cornell, oracle):
             d = s.desc()
             with pt.DeviceScene(s) as ds:
                 assert same_bits(ds.render_samples(c, p), oracle.render_samples(C.byref(d), c, p, math_mode=1))
+
+
+def test_small_work_areas(cornell, oracle):
+    """A sample buffer that holds only a few samples per pixel (several batches, sums carried from batch to
+    batch in sample order) and a path pool of 1024 slots (every slot reused hundreds of times) give the same
+    bits as the default work areas."""
+    scene, cam, dev = cornell
+    p = pt.make_params(128, 128, 4)
+    want = oracle.render(scene.ptr, cam, p, math_mode=1)
+    os.environ["PT_SAMPLE_BUFFER_MB"] = "1"   # 128*128*12 B per sample -> 5 samples per batch, 4 batches
+    os.environ["PT_WAVEFRONT_SLOTS"] = "1024"
+    try:
+        got = dev.render(cam, p)
+    finally:
+        del os.environ["PT_SAMPLE_BUFFER_MB"]
+        del os.environ["PT_WAVEFRONT_SLOTS"]
+    assert same_bits(got, want)
+    assert same_bits(dev.render(cam, p), want)
