@@ -56,7 +56,8 @@ struct Pool {
                    //   surface | kBackEmits | kDestIsSample
     float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
     uint2* retry;  // rays to trace again in storage order: (slot, or kRetryIsShadow | shadow-queue entry; bits of
-                   // the distance beyond which nothing needs to be looked at)
+                   // the distance beyond which nothing needs to be looked at), kRetryShards sub-lists
+    uint32_t retryCap; // entries per sub-list
     uint32_t nSlots;
     uint32_t nShards; // min(kShards, number of shading blocks): shard of a block = blockIdx % nShards
 };
@@ -75,7 +76,7 @@ struct Batch {
 //                 with blockIdx % S == q)
 //   S             slots that have run out of work
 //   S+1..3S       fill of the shadow-ray queue of shard q, double buffered by iteration parity
-//   3S+1          rays the nearer-child-first tracing left for the storage-order pass
+//   3S+1..3S+64   rays the nearer-child-first tracing left for the storage-order pass, per sub-list
 // Shards keep the returning atomics of one launch off a common address: one address serves
 // only about 90 of them per microsecond.  (Measured: one atomic per block on 8 shards beats one
 // per wave on 16..256 shards, which also fragments the shadow-ray queues.)
@@ -86,9 +87,10 @@ constexpr uint32_t kShards = PT_SHARDS;
 constexpr uint32_t kCtrStride = 32;
 constexpr uint32_t kCtrDone = kShards;
 constexpr uint32_t kCtrShadow = kShards + 1;
-constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // entries in the retry list
-[[maybe_unused]] constexpr uint32_t kCtrTiming = 3 * kShards + 2; // debug builds only
-constexpr uint32_t kCtrWords = (3 * kShards + 8) * kCtrStride;
+constexpr uint32_t kRetryShards = 64;            // sub-lists of the retry list (a wave appends to list wave % 64)
+constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entries in the retry sub-lists
+[[maybe_unused]] constexpr uint32_t kCtrTiming = kCtrRetry + kRetryShards; // debug builds only
+constexpr uint32_t kCtrWords = (kCtrTiming + 4) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
@@ -353,6 +355,24 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
 constexpr uint32_t kStackDepth = PT_STACK_DEPTH;
 constexpr float kTieBand = 1.0e-4f;
 
+constexpr uint32_t kRetryBuf = 128;
+
+// Move a wave's buffered retry entries to its sub-list of the retry list: one atomic per call.
+PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx, const uint2* buf, uint32_t n)
+{
+    if (n == 0)
+        return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the entries were written by other lanes of the wave
+    const uint32_t list = waveIdx % kRetryShards;
+    uint32_t base = 0;
+    if (laneId() == 0)
+        base = atomicAdd(&counters[(kCtrRetry + list) * kCtrStride], n);
+    base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+    for (uint32_t i = laneId(); i < n; i += 64u)
+        pool.retry[size_t(list) * pool.retryCap + base + i] = buf[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 #ifndef PT_ORDERED_WAVES
 #define PT_ORDERED_WAVES 1
 #endif
@@ -361,6 +381,8 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                                                           float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
 {
     __shared__ uint2 stack[kStackDepth][256];
+    __shared__ uint2 retryBuf[4][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
+    uint32_t nRetry = 0;                     // entries in this wave's part (the same in every lane)
     if (blockIdx.x == 0)
         for (uint32_t q = threadIdx.x; q < kShards; q += 256u)
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
@@ -520,25 +542,30 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                 }
             }
         }
-        if (have && walkOver) {
-            have = false;
-            const bool ambiguous = (best.sid != PT_NO_HIT && otherT <= cull) || dropGate <= cull;
-            // the lanes finishing together put their ambiguous rays on the retry list: one atomic
+        // rays that are through: ambiguous ones are collected per wave in LDS and go to the retry list
+        // in bulk (whole wave takes part in the bookkeeping)
+        const bool through = have && walkOver;
+        const bool ambiguous = through && ((best.sid != PT_NO_HIT && otherT <= cull) || dropGate <= cull);
+        {
             const uint64_t am = __builtin_amdgcn_ballot_w64(ambiguous);
             if (am != 0) {
-                uint32_t base = 0;
-                if (lane == uint32_t(__ffsll((long long)am) - 1))
-                    base = atomicAdd(&counters[kCtrRetry * kCtrStride], uint32_t(__popcll(am)));
-                base = uint32_t(__shfl(int(base), __ffsll((long long)am) - 1));
+                if (nRetry + 64u > kRetryBuf) {
+                    flushRetries(pool, counters, waveIdx, retryBuf[threadIdx.x >> 6], nRetry);
+                    nRetry = 0;
+                }
                 if (ambiguous) {
                     // what was found bounds the search of the second pass (same band once more)
                     float bound = best.sid != PT_NO_HIT ? cull * (1.0f + kTieBand) : kFltMax;
                     if (!(bound < kFltMax))
                         bound = kFltMax;
-                    pool.retry[base + uint32_t(__popcll(am & below))]
+                    retryBuf[threadIdx.x >> 6][nRetry + uint32_t(__popcll(am & below))]
                         = make_uint2(shadow ? (kRetryIsShadow | (itemBase + item)) : item, fbits(bound));
                 }
+                nRetry += uint32_t(__popcll(am));
             }
+        }
+        if (through) {
+            have = false;
             if (ambiguous) {
                 // settled by traceRetryKernel
             } else if (!shadow) {
@@ -563,6 +590,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
             }
         }
     }
+    flushRetries(pool, counters, waveIdx, retryBuf[threadIdx.x >> 6], nRetry);
 }
 
 // The rays traceOrderedKernel left over, each traced to completion in storage order (reference
@@ -574,9 +602,11 @@ template <bool DYN>
 __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters,
                                                         float* __restrict__ samples)
 {
-    const uint32_t n = counters[kCtrRetry * kCtrStride];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint2 entry = pool.retry[i];
+    // block b works on sub-list b % kRetryShards (the grid is a multiple of kRetryShards blocks)
+    const uint32_t list = blockIdx.x % kRetryShards;
+    const uint32_t n = counters[(kCtrRetry + list) * kCtrStride];
+    for (uint32_t i = (blockIdx.x / kRetryShards) * 256u + threadIdx.x; i < n; i += (gridDim.x / kRetryShards) * 256u) {
+        const uint2 entry = pool.retry[size_t(list) * pool.retryCap + i];
         const uint32_t e = entry.x;
         const float bound = __uint_as_float(entry.y);
         if (!(e & kRetryIsShadow)) {
@@ -644,8 +674,8 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
 {
     __shared__ uint32_t lds[2 * (kShadeWaves + 1)];
     const PathParams pp = a.pp;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        counters[kCtrRetry * kCtrStride] = 0; // the retry list of this iteration has been worked off
+    if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
+        counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
     PT_T_DECL();
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; // the grid covers the slots exactly
     PT_T(0);
@@ -879,9 +909,25 @@ uint32_t shadowCapOf(uint32_t nSlots)
     return (perShard + run - 1) / run * run;
 }
 
+// waves of one tracing launch: whole blocks of slot waves, then whole blocks of shadow-queue waves
+void traceWavesOf(uint32_t nSlots, uint32_t& slotWaves, uint32_t& shadowWaves)
+{
+    const uint32_t run = 64u * kItemsPerLane;
+    slotWaves = ((nSlots + run - 1) / run + 3u) / 4u * 4u;
+    shadowWaves = (shadowCapOf(nSlots) * kShards / run + 3u) / 4u * 4u;
+}
+
+// entries per retry sub-list: every wave of a tracing launch may put its whole run on its sub-list
+uint32_t retryCapOf(uint32_t nSlots)
+{
+    uint32_t slotWaves, shadowWaves;
+    traceWavesOf(nSlots, slotWaves, shadowWaves);
+    return (slotWaves + shadowWaves + kRetryShards - 1) / kRetryShards * (64u * kItemsPerLane);
+}
+
 size_t poolBytes(uint32_t n)
 {
-    return size_t(n) * (16 * 5 + 8 + 8) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 8);
+    return size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * 16 * 4 + size_t(retryCapOf(n)) * kRetryShards * 8;
 }
 
 Pool carvePool(void* base, uint32_t n)
@@ -904,7 +950,8 @@ Pool carvePool(void* base, uint32_t n)
     p.sh_c = static_cast<float4*>(take(q * 16));
     p.sh_b = static_cast<float4*>(take(q * 16));
     p.key = static_cast<uint2*>(take(size_t(n) * 8));
-    p.retry = static_cast<uint2*>(take((size_t(n) + q) * 8));
+    p.retryCap = retryCapOf(n);
+    p.retry = static_cast<uint2*>(take(size_t(p.retryCap) * kRetryShards * 8));
     p.nSlots = n;
     p.nShards = std::min<uint32_t>(kShards, n / kShadeBlock);
     return p;
@@ -954,22 +1001,23 @@ void launchTrace(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity)
 {
     WavefrontBuffers& w = sc->wf;
     const dim3 block(256);
-    const uint32_t run = 64u * kItemsPerLane;
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
-    // whole blocks of slot waves, then whole blocks of shadow-queue waves
-    const uint32_t slotWaves = ((pool.nSlots + run - 1) / run + 3u) / 4u * 4u;
-    const uint32_t shadowWaves = (shadowCap * kShards / run + 3u) / 4u * 4u;
+    uint32_t slotWaves, shadowWaves;
+    traceWavesOf(pool.nSlots, slotWaves, shadowWaves);
     const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
     const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
     // scenes in memory: nearer child first, then the few rays that leaves open in storage order
     const char* traversal = std::getenv("PT_TRAVERSAL");
     const bool referenceOrder = traversal && std::strcmp(traversal, "reference") == 0;
+    // (for scenes held in LDS the storage-order walk is the faster one: measured 353 against 610 us per launch)
     const bool ordered = !LDS && !referenceOrder;
     sc->kt.begin(KernelTimes::kTrace, stream);
     if (ordered) {
         hipLaunchKernelGGL((traceOrderedKernel<DYN>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity,
                            w.samples, shadowCap, slotWaves);
-        const uint32_t retryBlocks = std::min<uint32_t>(2048u, (pool.nSlots + shadowCap * kShards + 255u) / 256u);
+        // a multiple of kRetryShards blocks: a few per sub-list, more only for large pools
+        const uint32_t perList = std::min<uint32_t>(32u, std::max<uint32_t>(1u, pool.retryCap / 1024u));
+        const uint32_t retryBlocks = kRetryShards * perList;
         hipLaunchKernelGGL((traceRetryKernel<DYN>), dim3(retryBlocks), block, 0, stream, sc->dev, pool, w.counters,
                            w.samples);
     } else {
