@@ -328,3 +328,25 @@ def test_small_work_areas(cornell, oracle):
         del os.environ["PT_WAVEFRONT_SLOTS"]
     assert same_bits(got, want)
     assert same_bits(dev.render(cam, p), want)
+
+
+def test_dropin_program(tmp_path, oracle):
+    """oracle/_ref/dropin_demo is a program written against the reference's own classes whose pixel loop is
+    ptamd::render and whose 8-bit conversion is ptamd::to8Bit: what it renders through the binding and the
+    library equals the oracle's render of the flat scene the binding produced, bit for bit."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "dropin_demo")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_demo not present")
+    prefix = str(tmp_path / "demo")
+    w, h, s = 72, 48, 3
+    r = subprocess.run([exe, prefix, str(w), str(h), str(s)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img = np.fromfile(prefix + ".img", np.float32).reshape(h, w, 3)
+    u8 = np.fromfile(prefix + ".u8", np.uint8).reshape(h, w, 3)
+    scene = pt.LoadedScene(prefix + ".ptscene")
+    cam = pt.load_camera(prefix + ".ptcam")
+    want = oracle.render(scene.ptr, cam, pt.make_params(w, h, s, seed=42), math_mode=1)
+    assert same_bits(img, want)
+    assert np.array_equal(u8, oracle.image_to_8bit(img, flip_rows=False, math_mode=1))
+    assert img.mean() > 0.01
