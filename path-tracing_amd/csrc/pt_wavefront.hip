@@ -1105,7 +1105,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     perBatch = std::min<uint64_t>(perBatch, nsTotal);
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 22), idsPerSample * perBatch);
+    uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
     nSlots = std::max<uint64_t>((nSlots + kShadeBlock - 1) / kShadeBlock * kShadeBlock, kShadeBlock); // whole shading blocks
     int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
     if (rc != PT_OK)
