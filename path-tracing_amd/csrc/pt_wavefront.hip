@@ -188,7 +188,7 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 // (a leaf whose box was hit), done together.  The order of tests seen by one ray is
 // unchanged.
 #ifndef PT_ITEMS_PER_LANE
-#define PT_ITEMS_PER_LANE 4
+#define PT_ITEMS_PER_LANE 8
 #endif
 #ifndef PT_REFILL_LANES
 #define PT_REFILL_LANES 16
