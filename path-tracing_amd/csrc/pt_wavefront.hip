@@ -89,8 +89,7 @@ constexpr uint32_t kCtrDone = kShards;
 constexpr uint32_t kCtrShadow = kShards + 1;
 constexpr uint32_t kRetryShards = 64;            // sub-lists of the retry list (a wave appends to list wave % 64)
 constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entries in the retry sub-lists
-[[maybe_unused]] constexpr uint32_t kCtrTiming = kCtrRetry + kRetryShards; // debug builds only
-constexpr uint32_t kCtrWords = (kCtrTiming + 4) * kCtrStride;
+constexpr uint32_t kCtrWords = (kCtrRetry + kRetryShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
@@ -636,29 +635,6 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
     }
 }
 
-// Debug build only (-DPT_SHADE_TIMING): wave cycles per section of the shading kernel, summed
-// into spare counter lines (word (9 + k / 4) * 32 + k % 4 ... see PT_T_FLUSH) in units of 256 cycles.
-#ifdef PT_SHADE_TIMING
-#define PT_T_DECL() uint64_t ptT_last = __builtin_amdgcn_s_memtime(); uint32_t ptT_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PT_T(k)                                                                        \
-    do {                                                                               \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
-        const uint64_t now_ = __builtin_amdgcn_s_memtime();                            \
-        ptT_acc[k] += uint32_t(__builtin_amdgcn_readfirstlane(int(now_ - ptT_last))); \
-        ptT_last = now_;                                                               \
-    } while (0)
-#define PT_T_FLUSH()                                                                   \
-    do {                                                                               \
-        if (laneId() == 0)                                                             \
-            for (int k_ = 0; k_ < 12; k_++)                                            \
-                atomicAdd(&counters[(kCtrTiming + k_ / 4) * kCtrStride + 8 + (k_ % 4) * 2], ptT_acc[k_] >> 8); \
-    } while (0)
-#else
-#define PT_T_DECL()
-#define PT_T(k)
-#define PT_T_FLUSH()
-#endif
-
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 256
 #endif
@@ -676,9 +652,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
     const PathParams pp = a.pp;
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
-    PT_T_DECL();
     const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; // the grid covers the slots exactly
-    PT_T(0);
     // the whole record of the slot, whatever its state: one round trip to memory
     float4 d_s = pool.d_s[slot];
     float4 o_t = pool.o_t[slot];
@@ -686,7 +660,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
     float4 rad_p = pool.rad_p[slot];
     const uint4 hw = pool.hit[slot];
     const uint2 kw = pool.key[slot];
-    PT_T(1);
     const uint32_t state = (fbits(d_s.w) >> 16) & 3u;
     const bool active = state == kActive;
     bool finished = false;
@@ -721,10 +694,8 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
             hl.u = __uint_as_float(hw.z);
             hl.v = __uint_as_float(hw.w);
             Hit hr = makeHit(sc, ray, hl);
-            PT_T(2);
             Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng);
             radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
-            PT_T(3);
             if (sr.type == ScatterNone) {
                 finished = true;
             } else {
@@ -732,15 +703,12 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
                 if (sr.type == ScatterRandom && sc.n_lights > 0) {
                     float lightsP = lightsPdf<false>(sc, hr.position, sr.direction, ray.time, nullptr);
                     nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
-                    PT_T(4);
                     uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
                     if (lightIndex >= sc.n_lights)
                         lightIndex = sc.n_lights - 1;
                     const uint32_t lightSurf = sc.lights[lightIndex];
                     V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
-                    PT_T(5);
                     float lightDirP = lightsPdf<false>(sc, hr.position, lightDir, ray.time, nullptr);
-                    PT_T(6);
                     if (lightDirP > 0.0f) {
                         Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
                         if (lightSR.p > 0.0f) {
@@ -770,7 +738,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
                         }
                     }
                 }
-                PT_T(7);
                 throughput = nextThroughput;
                 ray = makeRay(hr.position, sr.direction, ray.time);
                 float maxT = max_(throughput.x, max_(throughput.y, throughput.z));
@@ -803,7 +770,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
         }
     }
 
-    PT_T(8);
     // two reservations with one atomic per block each, lanes ranked by ballots: a place in the
     // shard's shadow-ray queue, and a path number for every slot that is free now
     const bool want = state == kNeed || finished;
@@ -820,7 +786,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
             pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
     }
 
-    PT_T(9);
     if (want) {
         // shard q owns the groups of 64 path numbers g with g % nShards == q
         const uint32_t group = (local >> 6) * pool.nShards + shard, inTile = local & 63u;
@@ -852,14 +817,11 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
             pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
         }
     }
-    PT_T(10);
     // every lane stores its whole record (changed or not): whole cache lines per wave
     pool.o_t[slot] = o_t;
     pool.d_s[slot] = d_s;
     pool.thr_n[slot] = thr_n;
     pool.rad_p[slot] = rad_p;
-    PT_T(11);
-    PT_T_FLUSH();
 }
 
 // Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
@@ -1064,19 +1026,6 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool
         HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         sc->kt.collect();
-#ifdef PT_SHADE_TIMING
-        if (std::getenv("PT_SHADE_TIMING_PRINT")) {
-            static const char* names[12] = { "-", "state", "makeHit", "scatter+Le", "lightsPdf1", "lightSample", "lightsPdf2",
-                                             "toDirection+emission", "rr+finish", "reserve", "generate", "stores" };
-            double tot = 0;
-            for (int k = 0; k < 12; k++)
-                tot += w.hostCounters[(kCtrTiming + k / 4) * kCtrStride + 8 + (k % 4) * 2];
-            fprintf(stderr, "shade sections (%% of wave cycles, iter %llu):", (unsigned long long)iter);
-            for (int k = 0; k < 12; k++)
-                fprintf(stderr, " %s=%.1f", names[k], 100.0 * w.hostCounters[(kCtrTiming + k / 4) * kCtrStride + 8 + (k % 4) * 2] / tot);
-            fprintf(stderr, "\n");
-        }
-#endif
         if (w.hostCounters[kCtrDone * kCtrStride] >= pool.nSlots)
             break;
         if (iter > maxIters)
