@@ -74,13 +74,13 @@ struct WavefrontBuffers {
 // stream a kernel is launched on.  begin(k) / end() bracket one launch; collect() (once the
 // streams have been synchronised) adds the elapsed times to the sums.
 struct KernelTimes {
-    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kKinds };
+    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kKinds };
     bool enabled = false;
     std::vector<hipEvent_t> events; // pairs: start, stop
     std::vector<int> kinds;         // kind of pair i
     size_t used = 0;                // events in use
-    double ms[kKinds] = {0, 0, 0, 0};
-    uint64_t launches[kKinds] = {0, 0, 0, 0};
+    double ms[kKinds] = {0, 0, 0, 0, 0};
+    uint64_t launches[kKinds] = {0, 0, 0, 0, 0};
 
     void reset()
     {

@@ -58,6 +58,9 @@ struct Pool {
     uint2* retry;  // rays to trace again in storage order: (slot, or kRetryIsShadow | shadow-queue entry; bits of
                    // the distance beyond which nothing needs to be looked at), kRetryShards sub-lists
     uint32_t retryCap; // entries per sub-list
+    uint32_t* hitList;  // per shard: slots whose ray hit a surface (to be shaded)
+    uint32_t* freeList; // per shard: slots that take a new path (free, ray left the scene, or path finished)
+    uint32_t listCap;   // entries per shard of either list (= the slots of the shard's blocks, rounded up)
     uint32_t nSlots;
     uint32_t nShards; // min(kShards, number of shading blocks): shard of a block = blockIdx % nShards
 };
@@ -89,7 +92,10 @@ constexpr uint32_t kCtrDone = kShards;
 constexpr uint32_t kCtrShadow = kShards + 1;
 constexpr uint32_t kRetryShards = 64;            // sub-lists of the retry list (a wave appends to list wave % 64)
 constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entries in the retry sub-lists
-constexpr uint32_t kCtrWords = (kCtrRetry + kRetryShards) * kCtrStride;
+constexpr uint32_t kCtrHit = kCtrRetry + kRetryShards; // .. + S - 1: entries in the hit list of shard q
+constexpr uint32_t kCtrFree = kCtrHit + kShards;       // .. + S - 1: entries in the free list of shard q
+constexpr uint32_t kCtrLive = kCtrFree + kShards;       // .. + S - 1: continuing paths written to region q of the next pool
+constexpr uint32_t kCtrWords = (kCtrLive + kShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
@@ -206,8 +212,12 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     // the queues this iteration's shadeKernel fills were read by the previous launch of this
     // kernel; this launch reads the other set
     if (blockIdx.x == 0)
-        for (uint32_t q = threadIdx.x; q < kShards; q += 256u)
+        for (uint32_t q = threadIdx.x; q < kShards; q += 256u) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
+            counters[(kCtrHit + q) * kCtrStride] = 0; // the lists of the previous iteration have been worked off
+            counters[(kCtrFree + q) * kCtrStride] = 0;
+            counters[(kCtrLive + q) * kCtrStride] = 0;
+        }
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
     // per-lane gathers of the walk off the vector memory path
     extern __shared__ float4 ldsGeo[];
@@ -383,8 +393,12 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
     __shared__ uint2 retryBuf[4][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
     uint32_t nRetry = 0;                     // entries in this wave's part (the same in every lane)
     if (blockIdx.x == 0)
-        for (uint32_t q = threadIdx.x; q < kShards; q += 256u)
+        for (uint32_t q = threadIdx.x; q < kShards; q += 256u) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
+            counters[(kCtrHit + q) * kCtrStride] = 0; // the lists of the previous iteration have been worked off
+            counters[(kCtrFree + q) * kCtrStride] = 0;
+            counters[(kCtrLive + q) * kCtrStride] = 0;
+        }
     const float4* __restrict__ nodes = sc.nodes;
     const float4* __restrict__ wide = sc.wide;
     const float4* __restrict__ surf = sc.surf;
@@ -824,6 +838,251 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(De
     pool.rad_p[slot] = rad_p;
 }
 
+// ---- the shading step over compact lists, from one pool of path records into the other ----
+// Two pools of records take turns.  After the tracing of pool A:
+//   classifyKernel  one lane per record of A: records whose ray hit a surface go to the hit list,
+//                   records whose ray left the scene to the miss list (both per shard);
+//   shadeHitsKernel one lane per hit-list entry: the turn of the pathSample loop for a hit; a path
+//                   that goes on is written to the next free place of its shard's region of pool
+//                   B (dense, whole cache lines), a path that ends writes its sample;
+//   missKernel      one lane per miss-list entry: adds the environment, writes the sample;
+//   generateKernel  fills the rest of every region of B with new paths (path number by one atomic
+//                   per block, camera ray), or marks it empty when no paths are left.
+// Then B is traced.  Every wave of the heavy kernels is full of lanes doing the same kind of work,
+// records that need no shading are not loaded by the shading kernel, and all state stores are
+// dense.  New paths lie together in path-number order (neighbouring pixels), which also keeps the
+// camera rays of a wave and their first hits coherent.
+__global__ void __launch_bounds__(256) classifyKernel(Pool pool, uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t lds[2 * 5];
+    if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
+        counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x; // the grid covers the records exactly
+    const bool active = ((fbits(pool.d_s[slot].w) >> 16) & 3u) == kActive;
+    const bool hit = active && pool.hit[slot].x != PT_NO_HIT;
+    const bool miss = active && !hit;
+    const uint32_t shard = blockIdx.x % kShards;
+    uint32_t posH, posM;
+    blockReserve2<4>(&counters[(kCtrHit + shard) * kCtrStride], hit, &counters[(kCtrFree + shard) * kCtrStride], miss, lds,
+                     posH, posM);
+    if (hit)
+        pool.hitList[size_t(shard) * pool.listCap + posH] = slot;
+    if (miss)
+        pool.freeList[size_t(shard) * pool.listCap + posM] = slot;
+}
+
+__global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
+                                                                       uint32_t* __restrict__ counters, int parity,
+                                                                       float* __restrict__ samples, uint32_t shadowCap)
+{
+    __shared__ uint32_t lds[2 * 5];
+    // the block's 256 entries lie inside one shard's list (listCap is a multiple of 256)
+    const uint32_t first = blockIdx.x * 256u;
+    const uint32_t shard = first / pool.listCap;
+    const uint32_t fill = counters[(kCtrHit + shard) * kCtrStride];
+    if (first - shard * pool.listCap >= fill)
+        return; // the whole block lies beyond the list
+    const uint32_t entry = first - shard * pool.listCap + threadIdx.x;
+    const bool valid = entry < fill;
+    const uint32_t slot = valid ? pool.hitList[size_t(shard) * pool.listCap + entry] : 0u;
+    bool finished = false;
+    bool haveShadow = false;
+    V3 shOrigin, shDir, shC, shBack = v3(0.0f);
+    float shTime = 0.0f;
+    uint32_t shLight = 0;
+    uint32_t pathLocal = 0;
+    float4 nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nD = nO, nT = nO, nR = nO;
+    uint2 kw = make_uint2(0u, 0u);
+
+    if (valid) {
+        const float4 d_s = pool.d_s[slot];
+        const float4 o_t = pool.o_t[slot];
+        const float4 thr_n = pool.thr_n[slot];
+        const float4 rad_p = pool.rad_p[slot];
+        const uint4 hw = pool.hit[slot];
+        kw = pool.key[slot];
+        const int segment = int(fbits(d_s.w) & 0xFFFFu);
+        Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+        V3 throughput = v3(thr_n.x, thr_n.y, thr_n.z);
+        V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
+        pathLocal = fbits(rad_p.w);
+        Rng<false> rng;
+        rng.key = uint64_t(kw.x) | (uint64_t(kw.y) << 32);
+        rng.n = fbits(thr_n.w);
+        rng.cnt = nullptr;
+
+        // one turn of the loop of pathSample for a hit, reference src/15/pathtracer.cpp:63-127
+        HitLite hl;
+        hl.sid = hw.x & 0x7FFFFFFFu;
+        hl.backside = (hw.x >> 31) != 0;
+        hl.a = __uint_as_float(hw.y);
+        hl.u = __uint_as_float(hw.z);
+        hl.v = __uint_as_float(hw.w);
+        Hit hr = makeHit(sc, ray, hl);
+        Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng);
+        radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
+        if (sr.type == ScatterNone) {
+            finished = true;
+        } else {
+            V3 nextThroughput = throughput * sr.attenuation / sr.p;
+            if (sr.type == ScatterRandom && sc.n_lights > 0) {
+                float lightsP = lightsPdf<false>(sc, hr.position, sr.direction, ray.time, nullptr);
+                nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
+                uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
+                if (lightIndex >= sc.n_lights)
+                    lightIndex = sc.n_lights - 1;
+                const uint32_t lightSurf = sc.lights[lightIndex];
+                V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
+                float lightDirP = lightsPdf<false>(sc, hr.position, lightDir, ray.time, nullptr);
+                if (lightDirP > 0.0f) {
+                    Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
+                    if (lightSR.p > 0.0f) {
+                        float weight = powerHeuristicMIS(lightDirP, lightSR.p);
+                        // everything of the contribution but the light's emission, which the
+                        // shadow ray's hit decides
+                        shC = throughput * lightSR.attenuation / lightDirP * weight;
+                        shOrigin = hr.position;
+                        shDir = lightDir;
+                        shTime = ray.time;
+                        shLight = lightSurf;
+                        haveShadow = true;
+                        // emission of the chosen light, looked up here so that the tracing kernel
+                        // needs no material tables when the shadow ray arrives: the ray carries
+                        // contribution * emission for the light's front and, if that side emits
+                        // too, for its back
+                        int lmat;
+                        if (fbits(sc.surf[3 * size_t(lightSurf) + 0].w) <= kTriDynamic)
+                            lmat = int(sc.surfAttr[lightSurf].w & 0xFFFFFFu);
+                        else
+                            lmat = sc.spheres[sc.surfAttr[lightSurf].x].material;
+                        // (a black back side still matters if the product is NaN: NaN != 0)
+                        shBack = shC * materialLe(sc, lmat, true);
+                        if (shBack.x != 0.0f || shBack.y != 0.0f || shBack.z != 0.0f)
+                            shLight |= kBackEmits;
+                        shC = shC * materialLe(sc, lmat, false);
+                    }
+                }
+            }
+            throughput = nextThroughput;
+            ray = makeRay(hr.position, sr.direction, ray.time);
+            float maxT = max_(throughput.x, max_(throughput.y, throughput.z));
+            if (maxT < 1.0f && segment >= pp.rrStart) {
+                float q = 1.0f - maxT;
+                if (q > 0.95f)
+                    q = 0.95f;
+                if (rng.in01() < q) {
+                    finished = true;
+                } else {
+                    float rrWeight = 1.0f / (1.0f - q);
+                    throughput = throughput * rrWeight;
+                }
+            }
+            if (segment + 1 >= pp.maxSegments)
+                finished = true;
+        }
+        if (finished) {
+            float* p = samples + 3 * size_t(pathLocal);
+            p[0] = radiance.x;
+            p[1] = radiance.y;
+            p[2] = radiance.z;
+        } else {
+            nO = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
+            nD = make_float4(ray.direction.x, ray.direction.y, ray.direction.z,
+                             __uint_as_float((kActive << 16) | uint32_t(segment + 1)));
+            nT = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.n));
+            nR = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(pathLocal));
+        }
+    }
+
+    // two reservations with one atomic per block each: a place in the shard's shadow-ray queue,
+    // and the next free place in the shard's region of the other pool for every path that goes on
+    const bool goesOn = valid && !finished;
+    uint32_t pos, posN;
+    blockReserve2<4>(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
+                     &counters[(kCtrLive + shard) * kCtrStride], goesOn, lds, pos, posN);
+    const uint32_t place = shard * (next.nSlots / kShards) + posN;
+    if (goesOn) {
+        next.o_t[place] = nO;
+        next.d_s[place] = nD;
+        next.thr_n[place] = nT;
+        next.rad_p[place] = nR;
+        next.key[place] = kw;
+    }
+    if (haveShadow) {
+        const uint32_t e = shard * shadowCap + pos;
+        pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
+        pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : place));
+        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? kDestIsSample : 0u)));
+        if (shLight & kBackEmits)
+            pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
+    }
+}
+
+// paths whose ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
+__global__ void __launch_bounds__(256) missKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters,
+                                                  float* __restrict__ samples)
+{
+    const uint32_t first = blockIdx.x * 256u;
+    const uint32_t shard = first / pool.listCap;
+    const uint32_t fill = counters[(kCtrFree + shard) * kCtrStride];
+    const uint32_t entry = first - shard * pool.listCap + threadIdx.x;
+    if (entry >= fill)
+        return;
+    const uint32_t slot = pool.freeList[size_t(shard) * pool.listCap + entry];
+    const float4 rad_p = pool.rad_p[slot];
+    V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
+    if (sc.envmap.type != PT_ENV_NONE) {
+        const float4 thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
+        radiance = radiance + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
+    }
+    float* p = samples + 3 * size_t(fbits(rad_p.w));
+    p[0] = radiance.x;
+    p[1] = radiance.y;
+    p[2] = radiance.z;
+}
+
+// `next` = the pool being filled: the places of every region behind the paths that go on
+__global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, Batch b, uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t lds[2 * 5];
+    const uint32_t regionCap = next.nSlots / kShards; // a multiple of 256
+    const uint32_t first = blockIdx.x * 256u;
+    const uint32_t shard = first / regionCap;
+    const uint32_t goingOn = counters[(kCtrLive + shard) * kCtrStride];
+    if (first - shard * regionCap + 256u <= goingOn)
+        return; // the whole block holds paths that go on
+    const uint32_t place = first + threadIdx.x;
+    const bool want = place - shard * regionCap >= goingOn;
+    // a path number for every free place: one atomic per block
+    uint32_t local, unused;
+    blockReserve2<4>(&counters[shard * kCtrStride], want, &counters[shard * kCtrStride], false, lds, local, unused);
+    if (!want)
+        return;
+    // shard q owns the groups of 64 path numbers g with g % kShards == q
+    const uint32_t group = (local >> 6) * kShards + shard, inTile = local & 63u;
+    // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
+    const uint32_t tile = group / b.nS, sLocal = group % b.nS;
+    const int lx = int((tile % b.tilesX) * 8u + (inTile & 7u));
+    const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
+    if (group >= b.totalIds >> 6 || lx >= a.tw || ly >= a.th) {
+        // no paths left, or padding of an edge tile: the place stays empty in this iteration
+        next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNeed << 16));
+        return;
+    }
+    const int x = a.x0 + lx, y = a.y0 + ly;
+    const int smp = int(b.sFirst + sLocal);
+    Rng<false> rng;
+    rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
+    rng.n = 0;
+    rng.cnt = nullptr;
+    Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+    next.o_t[place] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
+    next.d_s[place] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
+    next.thr_n[place] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
+    next.rad_p[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sLocal * b.npix + uint32_t(ly * a.tw + lx)));
+    next.key[place] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
+}
+
 // Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
 __global__ void __launch_bounds__(256) resolveKernel(const float* __restrict__ samples, float* __restrict__ accum,
                                                      float* __restrict__ out, RenderArgs a, Batch b, int firstBatch,
@@ -889,10 +1148,12 @@ uint32_t retryCapOf(uint32_t nSlots)
 
 size_t poolBytes(uint32_t n)
 {
-    return size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * 16 * 4 + size_t(retryCapOf(n)) * kRetryShards * 8;
+    return 2 * size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 8)
+        + size_t(retryCapOf(n)) * kRetryShards * 8;
 }
 
-Pool carvePool(void* base, uint32_t n)
+// Two pools of path records that share the queues and lists.
+void carvePools(void* base, uint32_t n, Pool pools[2])
 {
     Pool p;
     char* c = static_cast<char*>(base);
@@ -901,22 +1162,27 @@ Pool carvePool(void* base, uint32_t n)
         c += bytes;
         return r;
     };
-    p.o_t = static_cast<float4*>(take(size_t(n) * 16));
-    p.d_s = static_cast<float4*>(take(size_t(n) * 16));
-    p.hit = static_cast<uint4*>(take(size_t(n) * 16));
-    p.thr_n = static_cast<float4*>(take(size_t(n) * 16));
-    p.rad_p = static_cast<float4*>(take(size_t(n) * 16));
     const size_t q = size_t(shadowCapOf(n)) * kShards;
     p.sh_o = static_cast<float4*>(take(q * 16));
     p.sh_d = static_cast<float4*>(take(q * 16));
     p.sh_c = static_cast<float4*>(take(q * 16));
     p.sh_b = static_cast<float4*>(take(q * 16));
-    p.key = static_cast<uint2*>(take(size_t(n) * 8));
     p.retryCap = retryCapOf(n);
     p.retry = static_cast<uint2*>(take(size_t(p.retryCap) * kRetryShards * 8));
+    p.listCap = shadowCapOf(n);
+    p.hitList = static_cast<uint32_t*>(take(q * 4));
+    p.freeList = static_cast<uint32_t*>(take(q * 4));
     p.nSlots = n;
     p.nShards = std::min<uint32_t>(kShards, n / kShadeBlock);
-    return p;
+    for (int k = 0; k < 2; k++) {
+        p.o_t = static_cast<float4*>(take(size_t(n) * 16));
+        p.d_s = static_cast<float4*>(take(size_t(n) * 16));
+        p.hit = static_cast<uint4*>(take(size_t(n) * 16));
+        p.thr_n = static_cast<float4*>(take(size_t(n) * 16));
+        p.rad_p = static_cast<float4*>(take(size_t(n) * 16));
+        p.key = static_cast<uint2*>(take(size_t(n) * 8));
+        pools[k] = p;
+    }
 }
 
 int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npix)
@@ -1002,37 +1268,78 @@ void launchTraceFor(pt_scene* sc, const Pool& pool, hipStream_t stream, int pari
 }
 
 // Run one batch of samples [b.sFirst, b.sFirst + b.nS) of every pixel of the tile into the sample buffer.
-int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool& pool, hipStream_t stream)
+int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools[2], hipStream_t stream)
 {
     WavefrontBuffers& w = sc->wf;
+    const uint32_t nSlots = pools[0].nSlots;
     HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(pool.d_s, 0, size_t(pool.nSlots) * 16, stream)); // every slot: no path yet
-    const uint64_t maxIters = (uint64_t(b.totalIds) / pool.nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
+    HIP_TRY(hipMemsetAsync(pools[0].d_s, 0, size_t(nSlots) * 16, stream)); // no paths yet
+    HIP_TRY(hipMemsetAsync(pools[1].d_s, 0, size_t(nSlots) * 16, stream));
+    const uint64_t maxIters = (uint64_t(b.totalIds) / nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const int checkEvery = 16;
     const bool dyn = sc->hasDynamic;
     const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
         && std::getenv("PT_NO_LDS_SCENE") == nullptr;
+    const char* shadeMode = std::getenv("PT_SHADE");
+    const bool compacting = !(shadeMode && std::strcmp(shadeMode, "fused") == 0);
+    const uint32_t shadowCap = shadowCapOf(nSlots);
+    const dim3 gridLists(pools[0].listCap / 256u * kShards), gridSlots(nSlots / 256u), block(256);
+    bool exhaustedBefore = false; // every path number had been handed out at the previous check already
     uint64_t iter = 0;
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
             const int parity = int(iter & 1);
-            launchTraceFor(sc, pool, stream, parity, dyn, lds);
+            if (!compacting) {
+                launchTraceFor(sc, pools[0], stream, parity, dyn, lds);
+                sc->kt.begin(KernelTimes::kShade, stream);
+                hipLaunchKernelGGL(shadeKernel, dim3(nSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, sc->dev, pools[0], a,
+                                   b, w.counters, parity, w.samples, shadowCap);
+                sc->kt.end(stream);
+                continue;
+            }
+            const Pool& cur = pools[iter & 1];
+            const Pool& next = pools[(iter + 1) & 1];
+            launchTraceFor(sc, cur, stream, parity, dyn, lds);
+            sc->kt.begin(KernelTimes::kClassify, stream);
+            hipLaunchKernelGGL(classifyKernel, gridSlots, block, 0, stream, cur, w.counters);
+            sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
-            hipLaunchKernelGGL(shadeKernel, dim3(pool.nSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, sc->dev, pool, a,
-                               b, w.counters, parity, w.samples, shadowCapOf(pool.nSlots));
+            hipLaunchKernelGGL(shadeHitsKernel, gridLists, block, 0, stream, sc->dev, cur, next, a.pp, w.counters, parity,
+                               w.samples, shadowCap);
+            sc->kt.end(stream);
+            sc->kt.begin(KernelTimes::kGenerate, stream);
+            hipLaunchKernelGGL(missKernel, gridLists, block, 0, stream, sc->dev, cur, w.counters, w.samples);
+            hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, next, a, b, w.counters);
             sc->kt.end(stream);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         sc->kt.collect();
-        if (w.hostCounters[kCtrDone * kCtrStride] >= pool.nSlots)
-            break;
+        if (!compacting) {
+            if (w.hostCounters[kCtrDone * kCtrStride] >= nSlots)
+                break;
+        } else {
+            // finished when no path was alive in the last iteration and every path number had been
+            // handed out well before it (so that its generateKernel cannot have started one)
+            uint64_t alive = 0;
+            bool exhausted = true;
+            for (uint32_t q = 0; q < kShards; q++) {
+                alive += w.hostCounters[(kCtrHit + q) * kCtrStride] + w.hostCounters[(kCtrFree + q) * kCtrStride]
+                    + w.hostCounters[(kCtrLive + q) * kCtrStride];
+                const uint64_t handedOut = w.hostCounters[q * kCtrStride]; // path numbers of shard q
+                if ((handedOut >> 6) * kShards + q < (b.totalIds >> 6))
+                    exhausted = false;
+            }
+            if (exhaustedBefore && alive == 0)
+                break;
+            exhaustedBefore = exhausted;
+        }
         if (iter > maxIters)
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
     // the last paths may have queued shadow rays in the very last shading launch: trace those
-    launchTraceFor(sc, pool, stream, int(iter & 1), dyn, lds);
+    launchTraceFor(sc, pools[compacting ? (iter & 1) : 0], stream, int(iter & 1), dyn, lds);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -1055,12 +1362,14 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
     uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
-    nSlots = std::max<uint64_t>((nSlots + kShadeBlock - 1) / kShadeBlock * kShadeBlock, kShadeBlock); // whole shading blocks
+    const uint64_t slotUnit = 256u * kShards; // every shard's region is whole blocks
+    nSlots = std::max<uint64_t>((nSlots + slotUnit - 1) / slotUnit * slotUnit, slotUnit);
     int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
     if (rc != PT_OK)
         return rc;
     WavefrontBuffers& w = sc->wf;
-    const Pool pool = carvePool(w.pool, uint32_t(nSlots));
+    Pool pools[2];
+    carvePools(w.pool, uint32_t(nSlots), pools);
     HIP_TRY(hipEventRecord(sc->evStart, stream));
     for (uint32_t s = 0; s < nsTotal; s += uint32_t(perBatch)) {
         Batch b;
@@ -1070,7 +1379,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
         b.sFirst = uint32_t(a.s0) + s;
         b.npix = uint32_t(npix);
         b.totalIds = uint32_t(idsPerSample * b.nS);
-        rc = runBatch(sc, a, b, pool, stream);
+        rc = runBatch(sc, a, b, pools, stream);
         if (rc != PT_OK)
             return rc;
         if (d_out) {
