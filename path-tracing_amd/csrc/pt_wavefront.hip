@@ -1,27 +1,32 @@
-// pt_wavefront.hip -- the wavefront renderer: generate / trace / shade kernels
-// over a pool of path slots in HBM, plus the resolve kernel.
+// pt_wavefront.hip -- the wavefront renderer: trace / classify / shade / generate
+// kernels over two pools of path records in HBM, plus the resolve kernel.
 //
-// One path = one (pixel, sample).  A fixed pool of path slots lives in HBM as
-// structure-of-arrays of 16-byte records; every iteration of the host loop runs
+// One path = one (pixel, sample).  Path records live in HBM as structure-of-arrays
+// of 16-byte rows, in two pools that take turns.  Every iteration of the host loop
+// runs, on the current pool,
 //
-//   traceKernel     closest hit (reference src/15/bvh.hpp:183-213) of the ray of
-//                   every live slot, and of every queued shadow ray: if that one
-//                   reaches the chosen light, the prepared contribution is added
-//                   (reference src/15/pathtracer.cpp:99-107);
-//   shadeKernel     one lane per slot: environment on a miss, else hit record,
-//                   scatter, emission, light pdfs, light sample, MIS, Russian
-//                   roulette (reference src/15/pathtracer.cpp:60-126); queues the
-//                   shadow ray; a finished path writes its radiance to the sample
-//                   buffer and its slot at once starts the next path: it draws a
-//                   path number (one atomic per block), computes the camera ray and
-//                   resets the path state (reference src/15/pathtracer.cpp:202-215,
-//                   camera.hpp:34-55).
+//   traceKernel       closest hit (reference src/15/bvh.hpp:183-213) of the ray of
+//   (or traceOrdered- every live record, and of every queued shadow ray: if that one
+//   Kernel + trace-   reaches the chosen light, the prepared contribution is added
+//   RetryKernel)      (reference src/15/pathtracer.cpp:99-107);
+//   classifyKernel    sorts the live records into a hit list and a miss list;
+//   shadeHitsKernel   per hit: hit record, scatter, emission, light pdfs, light sample,
+//                     MIS, Russian roulette (reference src/15/pathtracer.cpp:63-126);
+//                     queues the shadow ray; a path that goes on is written densely
+//                     into the other pool, a path that ends writes its radiance to
+//                     the sample buffer;
+//   missKernel        per miss: environment, radiance to the sample buffer
+//                     (reference src/15/pathtracer.cpp:60-62);
+//   generateKernel    fills the rest of the other pool with new paths: path number
+//                     (one atomic per block), camera ray, fresh path state
+//                     (reference src/15/pathtracer.cpp:202-215, camera.hpp:34-55);
 //
-// Finished radiances go to a sample buffer indexed [sample][pixel]; resolveKernel
-// then adds each pixel's samples in sample order -- the same sequence of float
-// additions as the reference's accumulation loop (src/15/pathtracer.cpp:207-220),
-// which keeps the image bit-identical to a sequential evaluation however the
-// paths were scheduled.  All arithmetic per path is that of pt_device.hpp.
+// and then the pools change roles.  Finished radiances go to a sample buffer indexed
+// [sample][pixel]; resolveKernel then adds each pixel's samples in sample order --
+// the same sequence of float additions as the reference's accumulation loop
+// (src/15/pathtracer.cpp:207-220), which keeps the image bit-identical to a
+// sequential evaluation however the paths were scheduled.  All arithmetic per path
+// is that of pt_device.hpp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -37,7 +42,7 @@ using ptint::fail;
 
 namespace {
 
-enum : uint32_t { kNeed = 0, kActive = 1, kDone = 2 };
+enum : uint32_t { kEmpty = 0, kActive = 1 }; // state of a record: no path / a path with a ray to trace
 constexpr uint32_t kDestIsSample = 0x80000000u;
 constexpr uint32_t kBackEmits = 0x40000000u;
 constexpr uint32_t kLightMask = 0x3FFFFFFFu;
@@ -51,18 +56,17 @@ struct Pool {
     float4* rad_p; // radiance so far, bits: index of the path in the sample buffer
     uint2* key;    // generator key of the path
     float4* sh_o;  // shadow ray queue: origin, time
-    float4* sh_d;  //   direction, bits: destination (slot or sample-buffer index)
+    float4* sh_d;  //   direction, bits: destination (record of the pool traced next, or sample-buffer index)
     float4* sh_c;  //   what to add if the ray reaches the front side of the chosen light, bits: light
                    //   surface | kBackEmits | kDestIsSample
     float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
     uint2* retry;  // rays to trace again in storage order: (slot, or kRetryIsShadow | shadow-queue entry; bits of
                    // the distance beyond which nothing needs to be looked at), kRetryShards sub-lists
     uint32_t retryCap; // entries per sub-list
-    uint32_t* hitList;  // per shard: slots whose ray hit a surface (to be shaded)
-    uint32_t* freeList; // per shard: slots that take a new path (free, ray left the scene, or path finished)
-    uint32_t listCap;   // entries per shard of either list (= the slots of the shard's blocks, rounded up)
-    uint32_t nSlots;
-    uint32_t nShards; // min(kShards, number of shading blocks): shard of a block = blockIdx % nShards
+    uint32_t* hitList;  // per shard: records whose ray hit a surface (to be shaded)
+    uint32_t* freeList; // per shard: records whose ray left the scene (to be finished)
+    uint32_t listCap;   // entries per shard of either list (= the records of the shard's blocks, rounded up)
+    uint32_t nSlots;    // records per pool: a multiple of 256 * kShards; shard q's region is [q, q + 1) * nSlots / kShards
 };
 
 // geometry of one batch of paths
@@ -75,11 +79,12 @@ struct Batch {
 };
 
 // Counters, one per 128-byte line (word index = line * 32), kShards = S:
-//   0..S-1        path numbers handed out by shard q (a shard = the blocks of the shading kernel
-//                 with blockIdx % S == q)
-//   S             slots that have run out of work
+//   0..S-1        path numbers handed out by shard q (a shard = the blocks of classifyKernel with
+//                 blockIdx % S == q, their lists, and region q of a pool)
 //   S+1..3S       fill of the shadow-ray queue of shard q, double buffered by iteration parity
 //   3S+1..3S+64   rays the nearer-child-first tracing left for the storage-order pass, per sub-list
+//   then S each   entries of the hit list, of the miss list, and paths written to region q of the
+//                 other pool in this iteration
 // Shards keep the returning atomics of one launch off a common address: one address serves
 // only about 90 of them per microsecond.  (Measured: one atomic per block on 8 shards beats one
 // per wave on 16..256 shards, which also fragments the shadow-ray queues.)
@@ -88,12 +93,11 @@ struct Batch {
 #endif
 constexpr uint32_t kShards = PT_SHARDS;
 constexpr uint32_t kCtrStride = 32;
-constexpr uint32_t kCtrDone = kShards;
 constexpr uint32_t kCtrShadow = kShards + 1;
 constexpr uint32_t kRetryShards = 64;            // sub-lists of the retry list (a wave appends to list wave % 64)
 constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entries in the retry sub-lists
 constexpr uint32_t kCtrHit = kCtrRetry + kRetryShards; // .. + S - 1: entries in the hit list of shard q
-constexpr uint32_t kCtrFree = kCtrHit + kShards;       // .. + S - 1: entries in the free list of shard q
+constexpr uint32_t kCtrFree = kCtrHit + kShards;       // .. + S - 1: entries in the miss list of shard q
 constexpr uint32_t kCtrLive = kCtrFree + kShards;       // .. + S - 1: continuing paths written to region q of the next pool
 constexpr uint32_t kCtrWords = (kCtrLive + kShards) * kCtrStride;
 
@@ -649,195 +653,9 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
     }
 }
 
-#ifndef PT_SHADE_BLOCK
-#define PT_SHADE_BLOCK 256
-#endif
-constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK; // threads per block of the shading kernel
-constexpr uint32_t kShadeWaves = kShadeBlock / 64u;
-
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
-__global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) shadeKernel(DevScene sc, Pool pool, RenderArgs a, Batch b,
-                                                              uint32_t* __restrict__ counters, int parity,
-                                                              float* __restrict__ samples, uint32_t shadowCap)
-{
-    __shared__ uint32_t lds[2 * (kShadeWaves + 1)];
-    const PathParams pp = a.pp;
-    if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
-        counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
-    const uint32_t slot = blockIdx.x * kShadeBlock + threadIdx.x; // the grid covers the slots exactly
-    // the whole record of the slot, whatever its state: one round trip to memory
-    float4 d_s = pool.d_s[slot];
-    float4 o_t = pool.o_t[slot];
-    float4 thr_n = pool.thr_n[slot];
-    float4 rad_p = pool.rad_p[slot];
-    const uint4 hw = pool.hit[slot];
-    const uint2 kw = pool.key[slot];
-    const uint32_t state = (fbits(d_s.w) >> 16) & 3u;
-    const bool active = state == kActive;
-    bool finished = false;
-    bool haveShadow = false;
-    V3 shOrigin, shDir, shC, shBack = v3(0.0f);
-    float shTime = 0.0f;
-    uint32_t shLight = 0;
-    V3 radiance = v3(0.0f);
-    uint32_t pathLocal = 0;
-
-    if (active) {
-        const int segment = int(fbits(d_s.w) & 0xFFFFu);
-        Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
-        V3 throughput = v3(thr_n.x, thr_n.y, thr_n.z);
-        radiance = v3(rad_p.x, rad_p.y, rad_p.z);
-        pathLocal = fbits(rad_p.w);
-        Rng<false> rng;
-        rng.key = uint64_t(kw.x) | (uint64_t(kw.y) << 32);
-        rng.n = fbits(thr_n.w);
-        rng.cnt = nullptr;
-
-        // one turn of the loop of pathSample, reference src/15/pathtracer.cpp:59-127
-        if (hw.x == PT_NO_HIT) {
-            if (sc.envmap.type != PT_ENV_NONE)
-                radiance = radiance + throughput * envmapValue(sc, ray.direction);
-            finished = true;
-        } else {
-            HitLite hl;
-            hl.sid = hw.x & 0x7FFFFFFFu;
-            hl.backside = (hw.x >> 31) != 0;
-            hl.a = __uint_as_float(hw.y);
-            hl.u = __uint_as_float(hw.z);
-            hl.v = __uint_as_float(hw.w);
-            Hit hr = makeHit(sc, ray, hl);
-            Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng);
-            radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
-            if (sr.type == ScatterNone) {
-                finished = true;
-            } else {
-                V3 nextThroughput = throughput * sr.attenuation / sr.p;
-                if (sr.type == ScatterRandom && sc.n_lights > 0) {
-                    float lightsP = lightsPdf<false>(sc, hr.position, sr.direction, ray.time, nullptr);
-                    nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
-                    uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
-                    if (lightIndex >= sc.n_lights)
-                        lightIndex = sc.n_lights - 1;
-                    const uint32_t lightSurf = sc.lights[lightIndex];
-                    V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
-                    float lightDirP = lightsPdf<false>(sc, hr.position, lightDir, ray.time, nullptr);
-                    if (lightDirP > 0.0f) {
-                        Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
-                        if (lightSR.p > 0.0f) {
-                            float weight = powerHeuristicMIS(lightDirP, lightSR.p);
-                            // everything of the contribution but the light's emission, which
-                            // the shadow ray's hit decides
-                            shC = throughput * lightSR.attenuation / lightDirP * weight;
-                            shOrigin = hr.position;
-                            shDir = lightDir;
-                            shTime = ray.time;
-                            shLight = lightSurf;
-                            haveShadow = true;
-                            // emission of the chosen light, looked up here so that the tracing
-                            // kernel needs no material tables when the shadow ray arrives: the
-                            // ray carries contribution * emission for the light's front and,
-                            // if that side emits too, for its back
-                            int lmat;
-                            if (fbits(sc.surf[3 * size_t(lightSurf) + 0].w) <= kTriDynamic)
-                                lmat = int(sc.surfAttr[lightSurf].w & 0xFFFFFFu);
-                            else
-                                lmat = sc.spheres[sc.surfAttr[lightSurf].x].material;
-                            // (a black back side still matters if the product is NaN: NaN != 0)
-                            shBack = shC * materialLe(sc, lmat, true);
-                            if (shBack.x != 0.0f || shBack.y != 0.0f || shBack.z != 0.0f)
-                                shLight |= kBackEmits;
-                            shC = shC * materialLe(sc, lmat, false);
-                        }
-                    }
-                }
-                throughput = nextThroughput;
-                ray = makeRay(hr.position, sr.direction, ray.time);
-                float maxT = max_(throughput.x, max_(throughput.y, throughput.z));
-                if (maxT < 1.0f && segment >= pp.rrStart) {
-                    float q = 1.0f - maxT;
-                    if (q > 0.95f)
-                        q = 0.95f;
-                    if (rng.in01() < q) {
-                        finished = true;
-                    } else {
-                        float rrWeight = 1.0f / (1.0f - q);
-                        throughput = throughput * rrWeight;
-                    }
-                }
-                if (segment + 1 >= pp.maxSegments)
-                    finished = true;
-            }
-        }
-        if (finished) {
-            float* p = samples + 3 * size_t(pathLocal);
-            p[0] = radiance.x;
-            p[1] = radiance.y;
-            p[2] = radiance.z;
-        } else {
-            o_t = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
-            d_s = make_float4(ray.direction.x, ray.direction.y, ray.direction.z,
-                              __uint_as_float((kActive << 16) | uint32_t(segment + 1)));
-            thr_n = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.n));
-            rad_p = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(pathLocal));
-        }
-    }
-
-    // two reservations with one atomic per block each, lanes ranked by ballots: a place in the
-    // shard's shadow-ray queue, and a path number for every slot that is free now
-    const bool want = state == kNeed || finished;
-    const uint32_t shard = blockIdx.x % pool.nShards;
-    uint32_t pos, local;
-    blockReserve2<kShadeWaves>(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
-                               &counters[shard * kCtrStride], want, lds, pos, local);
-    if (haveShadow) {
-        const uint32_t e = shard * shadowCap + pos;
-        pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
-        pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : slot));
-        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? kDestIsSample : 0u)));
-        if (shLight & kBackEmits)
-            pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
-    }
-
-    if (want) {
-        // shard q owns the groups of 64 path numbers g with g % nShards == q
-        const uint32_t group = (local >> 6) * pool.nShards + shard, inTile = local & 63u;
-        // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
-        const uint32_t tile = group / b.nS, sLocal = group % b.nS;
-        const int lx = int((tile % b.tilesX) * 8u + (inTile & 7u));
-        const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
-        if (group >= b.totalIds >> 6) {
-            // no paths left: the slot is out of work for the rest of the batch
-            d_s.w = __uint_as_float(kDone << 16);
-            const uint64_t m = __builtin_amdgcn_ballot_w64(true);
-            if (int(laneId()) == __ffsll((long long)m) - 1)
-                atomicAdd(&counters[kCtrDone * kCtrStride], uint32_t(__popcll(m)));
-        } else if (lx >= a.tw || ly >= a.th) {
-            // padding of an edge tile: not a path; the slot draws again next iteration
-            d_s.w = __uint_as_float(kNeed << 16);
-        } else {
-            const int x = a.x0 + lx, y = a.y0 + ly;
-            const int smp = int(b.sFirst + sLocal);
-            Rng<false> rng;
-            rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
-            rng.n = 0;
-            rng.cnt = nullptr;
-            Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
-            o_t = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
-            d_s = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
-            thr_n = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
-            rad_p = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sLocal * b.npix + uint32_t(ly * a.tw + lx)));
-            pool.key[slot] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
-        }
-    }
-    // every lane stores its whole record (changed or not): whole cache lines per wave
-    pool.o_t[slot] = o_t;
-    pool.d_s[slot] = d_s;
-    pool.thr_n[slot] = thr_n;
-    pool.rad_p[slot] = rad_p;
-}
-
 // ---- the shading step over compact lists, from one pool of path records into the other ----
 // Two pools of records take turns.  After the tracing of pool A:
 //   classifyKernel  one lane per record of A: records whose ray hit a surface go to the hit list,
@@ -1066,7 +884,7 @@ __global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, B
     const int ly = int((tile / b.tilesX) * 8u + (inTile >> 3));
     if (group >= b.totalIds >> 6 || lx >= a.tw || ly >= a.th) {
         // no paths left, or padding of an edge tile: the place stays empty in this iteration
-        next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNeed << 16));
+        next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
         return;
     }
     const int x = a.x0 + lx, y = a.y0 + ly;
@@ -1124,8 +942,8 @@ uint64_t envU64(const char* name, uint64_t dflt)
 // capacity of one shard's shadow queue: the slots of the blocks of that shard, rounded up to whole wave runs
 uint32_t shadowCapOf(uint32_t nSlots)
 {
-    const uint32_t blocks = nSlots / kShadeBlock;
-    const uint32_t perShard = (blocks + kShards - 1) / kShards * kShadeBlock;
+    const uint32_t blocks = nSlots / 256u;
+    const uint32_t perShard = (blocks + kShards - 1) / kShards * 256u;
     const uint32_t run = 64u * kItemsPerLane;
     return (perShard + run - 1) / run * run;
 }
@@ -1173,7 +991,6 @@ void carvePools(void* base, uint32_t n, Pool pools[2])
     p.hitList = static_cast<uint32_t*>(take(q * 4));
     p.freeList = static_cast<uint32_t*>(take(q * 4));
     p.nSlots = n;
-    p.nShards = std::min<uint32_t>(kShards, n / kShadeBlock);
     for (int k = 0; k < 2; k++) {
         p.o_t = static_cast<float4*>(take(size_t(n) * 16));
         p.d_s = static_cast<float4*>(take(size_t(n) * 16));
@@ -1280,8 +1097,6 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     const bool dyn = sc->hasDynamic;
     const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
         && std::getenv("PT_NO_LDS_SCENE") == nullptr;
-    const char* shadeMode = std::getenv("PT_SHADE");
-    const bool compacting = !(shadeMode && std::strcmp(shadeMode, "fused") == 0);
     const uint32_t shadowCap = shadowCapOf(nSlots);
     const dim3 gridLists(pools[0].listCap / 256u * kShards), gridSlots(nSlots / 256u), block(256);
     bool exhaustedBefore = false; // every path number had been handed out at the previous check already
@@ -1289,14 +1104,6 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
             const int parity = int(iter & 1);
-            if (!compacting) {
-                launchTraceFor(sc, pools[0], stream, parity, dyn, lds);
-                sc->kt.begin(KernelTimes::kShade, stream);
-                hipLaunchKernelGGL(shadeKernel, dim3(nSlots / kShadeBlock), dim3(kShadeBlock), 0, stream, sc->dev, pools[0], a,
-                                   b, w.counters, parity, w.samples, shadowCap);
-                sc->kt.end(stream);
-                continue;
-            }
             const Pool& cur = pools[iter & 1];
             const Pool& next = pools[(iter + 1) & 1];
             launchTraceFor(sc, cur, stream, parity, dyn, lds);
@@ -1316,30 +1123,25 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
         HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         sc->kt.collect();
-        if (!compacting) {
-            if (w.hostCounters[kCtrDone * kCtrStride] >= nSlots)
-                break;
-        } else {
-            // finished when no path was alive in the last iteration and every path number had been
-            // handed out well before it (so that its generateKernel cannot have started one)
-            uint64_t alive = 0;
-            bool exhausted = true;
-            for (uint32_t q = 0; q < kShards; q++) {
-                alive += w.hostCounters[(kCtrHit + q) * kCtrStride] + w.hostCounters[(kCtrFree + q) * kCtrStride]
-                    + w.hostCounters[(kCtrLive + q) * kCtrStride];
-                const uint64_t handedOut = w.hostCounters[q * kCtrStride]; // path numbers of shard q
-                if ((handedOut >> 6) * kShards + q < (b.totalIds >> 6))
-                    exhausted = false;
-            }
-            if (exhaustedBefore && alive == 0)
-                break;
-            exhaustedBefore = exhausted;
+        // finished when no path was alive in the last iteration and every path number had been
+        // handed out well before it (so that its generateKernel cannot have started one)
+        uint64_t alive = 0;
+        bool exhausted = true;
+        for (uint32_t q = 0; q < kShards; q++) {
+            alive += w.hostCounters[(kCtrHit + q) * kCtrStride] + w.hostCounters[(kCtrFree + q) * kCtrStride]
+                + w.hostCounters[(kCtrLive + q) * kCtrStride];
+            const uint64_t handedOut = w.hostCounters[q * kCtrStride]; // path numbers of shard q
+            if ((handedOut >> 6) * kShards + q < (b.totalIds >> 6))
+                exhausted = false;
         }
+        if (exhaustedBefore && alive == 0)
+            break;
+        exhaustedBefore = exhausted;
         if (iter > maxIters)
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
     // the last paths may have queued shadow rays in the very last shading launch: trace those
-    launchTraceFor(sc, pools[compacting ? (iter & 1) : 0], stream, int(iter & 1), dyn, lds);
+    launchTraceFor(sc, pools[iter & 1], stream, int(iter & 1), dyn, lds);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
