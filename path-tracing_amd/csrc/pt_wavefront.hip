@@ -43,6 +43,7 @@ using ptint::fail;
 namespace {
 
 enum : uint32_t { kEmpty = 0, kActive = 1 }; // state of a record: no path / a path with a ray to trace
+enum : uint8_t { kClsEmpty = 0, kClsHit = 1, kClsMiss = 2 };
 constexpr uint32_t kDestIsSample = 0x80000000u;
 constexpr uint32_t kBackEmits = 0x40000000u;
 constexpr uint32_t kLightMask = 0x3FFFFFFFu;
@@ -55,6 +56,8 @@ struct Pool {
     float4* thr_n; // throughput, bits: number of random draws made
     float4* rad_p; // radiance so far, bits: index of the path in the sample buffer
     uint2* key;    // generator key of the path
+    uint8_t* cls;  // what the tracing found for the record: kClsEmpty / kClsHit / kClsMiss (classifyKernel reads
+                   // only this byte per record)
     float4* sh_o;  // shadow ray queue: origin, time
     float4* sh_d;  //   direction, bits: destination (record of the pool traced next, or sample-buffer index)
     float4* sh_c;  //   what to add if the ray reaches the front side of the chosen light, bits: light
@@ -66,7 +69,7 @@ struct Pool {
     uint32_t* hitList;  // per shard: records whose ray hit a surface (to be shaded)
     uint32_t* freeList; // per shard: records whose ray left the scene (to be finished)
     uint32_t listCap;   // entries per shard of either list (= the records of the shard's blocks, rounded up)
-    uint32_t nSlots;    // records per pool: a multiple of 256 * kShards; shard q's region is [q, q + 1) * nSlots / kShards
+    uint32_t nSlots;    // records per pool: a multiple of 1024 * kShards; shard q's region is [q, q + 1) * nSlots / kShards
 };
 
 // geometry of one batch of paths
@@ -334,6 +337,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
             if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
+                pool.cls[item] = best.sid == PT_NO_HIT ? kClsMiss : kClsHit;
             } else {
                 shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
             }
@@ -588,6 +592,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
             } else if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
+                pool.cls[item] = best.sid == PT_NO_HIT ? kClsMiss : kClsHit;
             } else if (best.sid != PT_NO_HIT) {
                 const float4 payload = pool.sh_c[itemBase + item];
                 if (best.sid == (fbits(payload.w) & kLightMask)) {
@@ -632,6 +637,7 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
             const HitLite best = closestHit<false, DYN>(sc, ray, 0.0001f, bound, nullptr);
             pool.hit[e] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                      fbits(best.a), fbits(best.u), fbits(best.v));
+            pool.cls[e] = best.sid == PT_NO_HIT ? kClsMiss : kClsHit;
         } else {
             const uint32_t q = e & ~kRetryIsShadow;
             const float4 so = pool.sh_o[q], sd = pool.sh_d[q], payload = pool.sh_c[q];
@@ -670,19 +676,20 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
 // records that need no shading are not loaded by the shading kernel, and all state stores are
 // dense.  New paths lie together in path-number order (neighbouring pixels), which also keeps the
 // camera rays of a wave and their first hits coherent.
-__global__ void __launch_bounds__(256) classifyKernel(Pool pool, uint32_t* __restrict__ counters)
+// (1024 threads per block: the two atomics per block are what bounds this kernel)
+constexpr uint32_t kClassifyBlock = 1024;
+__global__ void __launch_bounds__(kClassifyBlock) classifyKernel(Pool pool, uint32_t* __restrict__ counters)
 {
-    __shared__ uint32_t lds[2 * 5];
+    __shared__ uint32_t lds[2 * (kClassifyBlock / 64 + 1)];
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x; // the grid covers the records exactly
-    const bool active = ((fbits(pool.d_s[slot].w) >> 16) & 3u) == kActive;
-    const bool hit = active && pool.hit[slot].x != PT_NO_HIT;
-    const bool miss = active && !hit;
+    const uint32_t slot = blockIdx.x * kClassifyBlock + threadIdx.x; // the grid covers the records exactly
+    const uint8_t cls = pool.cls[slot];
+    const bool hit = cls == kClsHit, miss = cls == kClsMiss;
     const uint32_t shard = blockIdx.x % kShards;
     uint32_t posH, posM;
-    blockReserve2<4>(&counters[(kCtrHit + shard) * kCtrStride], hit, &counters[(kCtrFree + shard) * kCtrStride], miss, lds,
-                     posH, posM);
+    blockReserve2<kClassifyBlock / 64>(&counters[(kCtrHit + shard) * kCtrStride], hit,
+                                       &counters[(kCtrFree + shard) * kCtrStride], miss, lds, posH, posM);
     if (hit)
         pool.hitList[size_t(shard) * pool.listCap + posH] = slot;
     if (miss)
@@ -885,6 +892,7 @@ __global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, B
     if (group >= b.totalIds >> 6 || lx >= a.tw || ly >= a.th) {
         // no paths left, or padding of an edge tile: the place stays empty in this iteration
         next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
+        next.cls[place] = kClsEmpty;
         return;
     }
     const int x = a.x0 + lx, y = a.y0 + ly;
@@ -966,7 +974,7 @@ uint32_t retryCapOf(uint32_t nSlots)
 
 size_t poolBytes(uint32_t n)
 {
-    return 2 * size_t(n) * (16 * 5 + 8) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 8)
+    return 2 * size_t(n) * (16 * 5 + 8 + 1) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 8)
         + size_t(retryCapOf(n)) * kRetryShards * 8;
 }
 
@@ -998,6 +1006,7 @@ void carvePools(void* base, uint32_t n, Pool pools[2])
         p.thr_n = static_cast<float4*>(take(size_t(n) * 16));
         p.rad_p = static_cast<float4*>(take(size_t(n) * 16));
         p.key = static_cast<uint2*>(take(size_t(n) * 8));
+        p.cls = static_cast<uint8_t*>(take(size_t(n)));
         pools[k] = p;
     }
 }
@@ -1092,6 +1101,7 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(pools[0].d_s, 0, size_t(nSlots) * 16, stream)); // no paths yet
     HIP_TRY(hipMemsetAsync(pools[1].d_s, 0, size_t(nSlots) * 16, stream));
+    HIP_TRY(hipMemsetAsync(pools[0].cls, kClsEmpty, size_t(nSlots), stream));
     const uint64_t maxIters = (uint64_t(b.totalIds) / nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const int checkEvery = 16;
     const bool dyn = sc->hasDynamic;
@@ -1108,7 +1118,7 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             const Pool& next = pools[(iter + 1) & 1];
             launchTraceFor(sc, cur, stream, parity, dyn, lds);
             sc->kt.begin(KernelTimes::kClassify, stream);
-            hipLaunchKernelGGL(classifyKernel, gridSlots, block, 0, stream, cur, w.counters);
+            hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyBlock), dim3(kClassifyBlock), 0, stream, cur, w.counters);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
             hipLaunchKernelGGL(shadeHitsKernel, gridLists, block, 0, stream, sc->dev, cur, next, a.pp, w.counters, parity,
@@ -1164,7 +1174,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
     uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
-    const uint64_t slotUnit = 256u * kShards; // every shard's region is whole blocks
+    const uint64_t slotUnit = uint64_t(kClassifyBlock) * kShards; // every shard's region and list is whole blocks
     nSlots = std::max<uint64_t>((nSlots + slotUnit - 1) / slotUnit * slotUnit, slotUnit);
     int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
     if (rc != PT_OK)
