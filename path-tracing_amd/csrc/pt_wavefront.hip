@@ -662,6 +662,10 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256
+#endif
+constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK; // threads per block of shadeHitsKernel
 // ---- the shading step over compact lists, from one pool of path records into the other ----
 // Two pools of records take turns.  After the tracing of pool A:
 //   classifyKernel  one lane per record of A: records whose ray hit a surface go to the hit list,
@@ -696,13 +700,13 @@ __global__ void __launch_bounds__(kClassifyBlock) classifyKernel(Pool pool, uint
         pool.freeList[size_t(shard) * pool.listCap + posM] = slot;
 }
 
-__global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
+__global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
                                                                        uint32_t* __restrict__ counters, int parity,
                                                                        float* __restrict__ samples, uint32_t shadowCap)
 {
-    __shared__ uint32_t lds[2 * 5];
-    // the block's 256 entries lie inside one shard's list (listCap is a multiple of 256)
-    const uint32_t first = blockIdx.x * 256u;
+    __shared__ uint32_t lds[2 * (kShadeBlock / 64 + 1)];
+    // the block's entries lie inside one shard's list (listCap is a multiple of the block size)
+    const uint32_t first = blockIdx.x * kShadeBlock;
     const uint32_t shard = first / pool.listCap;
     const uint32_t fill = counters[(kCtrHit + shard) * kCtrStride];
     if (first - shard * pool.listCap >= fill)
@@ -823,7 +827,7 @@ __global__ void __launch_bounds__(256, PT_SHADE_WAVES) shadeHitsKernel(DevScene 
     // and the next free place in the shard's region of the other pool for every path that goes on
     const bool goesOn = valid && !finished;
     uint32_t pos, posN;
-    blockReserve2<4>(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
+    blockReserve2<kShadeBlock / 64>(&counters[(kCtrShadow + parity * kShards + shard) * kCtrStride], haveShadow,
                      &counters[(kCtrLive + shard) * kCtrStride], goesOn, lds, pos, posN);
     const uint32_t place = shard * (next.nSlots / kShards) + posN;
     if (goesOn) {
@@ -1121,8 +1125,8 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyBlock), dim3(kClassifyBlock), 0, stream, cur, w.counters);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
-            hipLaunchKernelGGL(shadeHitsKernel, gridLists, block, 0, stream, sc->dev, cur, next, a.pp, w.counters, parity,
-                               w.samples, shadowCap);
+            hipLaunchKernelGGL(shadeHitsKernel, dim3(pools[0].listCap / kShadeBlock * kShards), dim3(kShadeBlock), 0, stream,
+                               sc->dev, cur, next, a.pp, w.counters, parity, w.samples, shadowCap);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kGenerate, stream);
             hipLaunchKernelGGL(missKernel, gridLists, block, 0, stream, sc->dev, cur, w.counters, w.samples);
