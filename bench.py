@@ -264,7 +264,7 @@ def main():
         # the reference algorithm's bytes, split by the kernel that does that part of the work
         kernel_bytes_ps = {
             "traceKernel": (cnt["node_visits"] * 32 + cnt["leaf_tests"] * 48) / n_s,
-            "shadeKernel": cnt["light_tests"] * 48 / n_s + 12,
+            "shadeHitsKernel": cnt["light_tests"] * 48 / n_s + 12,
         }
         kernels = {}
         for name, (launches, total_ms) in kernel_times.items():

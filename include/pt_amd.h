@@ -294,8 +294,9 @@ int pt_render_counted(pt_scene* scene, const pt_camera* camera, const pt_render_
  * this scene (HIP events on the launch stream); negative if none yet. */
 float pt_last_kernel_ms(pt_scene* scene);
 
-/* Device time per kernel of the wavefront renderer (generate, trace, shade,
- * resolve), measured with HIP events recorded on the launch stream between the
+/* Device time per kernel of the wavefront renderer (generateKernel, traceKernel
+ * = every tracing kernel of one step, classifyKernel, shadeHitsKernel,
+ * missKernel, resolveKernel), measured with HIP events recorded on the launch stream between the
  * kernels.  The reference has no counterpart (it has one loop and no kernels);
  * this is what a benchmark prices against the hardware's limits.
  * pt_scene_profile(scene, 1) clears the sums and switches the events on for the

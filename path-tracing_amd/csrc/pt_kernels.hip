@@ -617,8 +617,8 @@ int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, in
     DeviceGuard g(scene->device);
     HIP_TRY(hipDeviceSynchronize());
     scene->kt.collect();
-    static const char* const names[KernelTimes::kKinds] = { "generateKernel", "traceKernel", "shadeKernel",
-                                                            "resolveKernel", "classifyKernel" };
+    static const char* const names[KernelTimes::kKinds] = { "generateKernel", "traceKernel", "shadeHitsKernel",
+                                                            "resolveKernel", "classifyKernel", "missKernel" };
     *count = KernelTimes::kKinds;
     for (int k = 0; k < KernelTimes::kKinds && k < capacity; k++) {
         std::memset(&out[k], 0, sizeof(out[k]));

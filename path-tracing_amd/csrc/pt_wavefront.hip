@@ -1128,8 +1128,10 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             hipLaunchKernelGGL(shadeHitsKernel, dim3(pools[0].listCap / kShadeBlock * kShards), dim3(kShadeBlock), 0, stream,
                                sc->dev, cur, next, a.pp, w.counters, parity, w.samples, shadowCap);
             sc->kt.end(stream);
-            sc->kt.begin(KernelTimes::kGenerate, stream);
+            sc->kt.begin(KernelTimes::kMiss, stream);
             hipLaunchKernelGGL(missKernel, gridLists, block, 0, stream, sc->dev, cur, w.counters, w.samples);
+            sc->kt.end(stream);
+            sc->kt.begin(KernelTimes::kGenerate, stream);
             hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, next, a, b, w.counters);
             sc->kt.end(stream);
         }

@@ -189,7 +189,7 @@ def test_kernel_times_are_recorded(cornell):
     times = dev.kernel_times()
     dev.profile(False)
     assert times["traceKernel"][0] > 0 and times["traceKernel"][1] > 0.0
-    assert times["shadeKernel"][0] > 0 and times["shadeKernel"][1] > 0.0
+    assert times["shadeHitsKernel"][0] > 0 and times["shadeHitsKernel"][1] > 0.0
     assert times["resolveKernel"][0] == 1
 
 
