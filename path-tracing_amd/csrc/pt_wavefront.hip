@@ -208,6 +208,9 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #ifndef PT_WALK_LANES
 #define PT_WALK_LANES 24
 #endif
+#ifndef PT_WALK_UNROLL
+#define PT_WALK_UNROLL 2
+#endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
@@ -323,6 +326,16 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
                 if (walking)
                     nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
                 walking = have && pending == kInner && cur < sc.n_nodes;
+#if PT_WALK_UNROLL >= 2
+                if (walking)
+                    nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
+                walking = have && pending == kInner && cur < sc.n_nodes;
+#endif
+#if PT_WALK_UNROLL >= 3
+                if (walking)
+                    nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
+                walking = have && pending == kInner && cur < sc.n_nodes;
+#endif
                 if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
                     break;
             }
@@ -848,9 +861,13 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
 }
 
 // paths whose ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
-__global__ void __launch_bounds__(256) missKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters,
+__global__ void __launch_bounds__(256) missKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
                                                   float* __restrict__ samples)
 {
+    // path numbers for generateKernel, which follows: it fills what the continuing paths leave free of
+    // every region of the other pool (nobody else touches these counters in between)
+    if (blockIdx.x == 0 && threadIdx.x < kShards)
+        counters[threadIdx.x * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + threadIdx.x) * kCtrStride];
     const uint32_t first = blockIdx.x * 256u;
     const uint32_t shard = first / pool.listCap;
     const uint32_t fill = counters[(kCtrFree + shard) * kCtrStride];
@@ -873,20 +890,17 @@ __global__ void __launch_bounds__(256) missKernel(DevScene sc, Pool pool, const 
 // `next` = the pool being filled: the places of every region behind the paths that go on
 __global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, Batch b, uint32_t* __restrict__ counters)
 {
-    __shared__ uint32_t lds[2 * 5];
     const uint32_t regionCap = next.nSlots / kShards; // a multiple of 256
     const uint32_t first = blockIdx.x * 256u;
     const uint32_t shard = first / regionCap;
     const uint32_t goingOn = counters[(kCtrLive + shard) * kCtrStride];
-    if (first - shard * regionCap + 256u <= goingOn)
-        return; // the whole block holds paths that go on
+    const uint32_t inRegion = first - shard * regionCap + threadIdx.x;
+    if (inRegion < goingOn)
+        return; // a path that goes on
+    // the free places of a region are one run, so their path numbers need no reservation: missKernel
+    // has advanced the shard's counter past this launch's numbers already
     const uint32_t place = first + threadIdx.x;
-    const bool want = place - shard * regionCap >= goingOn;
-    // a path number for every free place: one atomic per block
-    uint32_t local, unused;
-    blockReserve2<4>(&counters[shard * kCtrStride], want, &counters[shard * kCtrStride], false, lds, local, unused);
-    if (!want)
-        return;
+    const uint32_t local = counters[shard * kCtrStride] - (regionCap - inRegion);
     // shard q owns the groups of 64 path numbers g with g % kShards == q
     const uint32_t group = (local >> 6) * kShards + shard, inTile = local & 63u;
     // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
