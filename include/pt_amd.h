@@ -296,7 +296,7 @@ float pt_last_kernel_ms(pt_scene* scene);
 
 /* Device time per kernel of the wavefront renderer (generateKernel, traceKernel
  * = every tracing kernel of one step, classifyKernel, shadeHitsKernel,
- * missKernel, resolveKernel), measured with HIP events recorded on the launch stream between the
+ * resolveKernel), measured with HIP events recorded on the launch stream between the
  * kernels.  The reference has no counterpart (it has one loop and no kernels);
  * this is what a benchmark prices against the hardware's limits.
  * pt_scene_profile(scene, 1) clears the sums and switches the events on for the

@@ -74,7 +74,7 @@ struct WavefrontBuffers {
 // stream a kernel is launched on.  begin(k) / end() bracket one launch; collect() (once the
 // streams have been synchronised) adds the elapsed times to the sums.
 struct KernelTimes {
-    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kMiss, kKinds };
+    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kKinds };
     bool enabled = false;
     std::vector<hipEvent_t> events; // pairs: start, stop
     std::vector<int> kinds;         // kind of pair i

@@ -9,16 +9,16 @@
 //   (or traceOrdered- every live record, and of every queued shadow ray: if that one
 //   Kernel + trace-   reaches the chosen light, the prepared contribution is added
 //   RetryKernel)      (reference src/15/pathtracer.cpp:99-107);
-//   classifyKernel    sorts the live records into a hit list and a miss list;
+//   classifyKernel    puts the records whose ray hit a surface on a hit list and finishes
+//                     the ones whose ray left the scene: environment, radiance to the
+//                     sample buffer (reference src/15/pathtracer.cpp:60-62);
 //   shadeHitsKernel   per hit: hit record, scatter, emission, light pdfs, light sample,
 //                     MIS, Russian roulette (reference src/15/pathtracer.cpp:63-126);
 //                     queues the shadow ray; a path that goes on is written densely
 //                     into the other pool, a path that ends writes its radiance to
 //                     the sample buffer;
-//   missKernel        per miss: environment, radiance to the sample buffer
-//                     (reference src/15/pathtracer.cpp:60-62);
-//   generateKernel    fills the rest of the other pool with new paths: path number
-//                     (one atomic per block), camera ray, fresh path state
+//   generateKernel    fills the rest of the other pool with new paths: path number,
+//                     camera ray, fresh path state
 //                     (reference src/15/pathtracer.cpp:202-215, camera.hpp:34-55);
 //
 // and then the pools change roles.  Finished radiances go to a sample buffer indexed
@@ -67,7 +67,6 @@ struct Pool {
                    // the distance beyond which nothing needs to be looked at), kRetryShards sub-lists
     uint32_t retryCap; // entries per sub-list
     uint32_t* hitList;  // per shard: records whose ray hit a surface (to be shaded)
-    uint32_t* freeList; // per shard: records whose ray left the scene (to be finished)
     uint32_t listCap;   // entries per shard of either list (= the records of the shard's blocks, rounded up)
     uint32_t nSlots;    // records per pool: a multiple of 1024 * kShards; shard q's region is [q, q + 1) * nSlots / kShards
 };
@@ -100,8 +99,7 @@ constexpr uint32_t kCtrShadow = kShards + 1;
 constexpr uint32_t kRetryShards = 64;            // sub-lists of the retry list (a wave appends to list wave % 64)
 constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entries in the retry sub-lists
 constexpr uint32_t kCtrHit = kCtrRetry + kRetryShards; // .. + S - 1: entries in the hit list of shard q
-constexpr uint32_t kCtrFree = kCtrHit + kShards;       // .. + S - 1: entries in the miss list of shard q
-constexpr uint32_t kCtrLive = kCtrFree + kShards;       // .. + S - 1: continuing paths written to region q of the next pool
+constexpr uint32_t kCtrLive = kCtrHit + kShards;        // .. + S - 1: continuing paths written to region q of the next pool
 constexpr uint32_t kCtrWords = (kCtrLive + kShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
@@ -224,8 +222,10 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     if (blockIdx.x == 0)
         for (uint32_t q = threadIdx.x; q < kShards; q += 256u) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
-            counters[(kCtrHit + q) * kCtrStride] = 0; // the lists of the previous iteration have been worked off
-            counters[(kCtrFree + q) * kCtrStride] = 0;
+            counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
+            // the generateKernel before this launch gave path numbers to the places of region q that the
+            // continuing paths had left free
+            counters[q * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride];
             counters[(kCtrLive + q) * kCtrStride] = 0;
         }
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
@@ -416,8 +416,10 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
     if (blockIdx.x == 0)
         for (uint32_t q = threadIdx.x; q < kShards; q += 256u) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
-            counters[(kCtrHit + q) * kCtrStride] = 0; // the lists of the previous iteration have been worked off
-            counters[(kCtrFree + q) * kCtrStride] = 0;
+            counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
+            // the generateKernel before this launch gave path numbers to the places of region q that the
+            // continuing paths had left free
+            counters[q * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride];
             counters[(kCtrLive + q) * kCtrStride] = 0;
         }
     const float4* __restrict__ nodes = sc.nodes;
@@ -681,36 +683,49 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
 constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK; // threads per block of shadeHitsKernel
 // ---- the shading step over compact lists, from one pool of path records into the other ----
 // Two pools of records take turns.  After the tracing of pool A:
-//   classifyKernel  one lane per record of A: records whose ray hit a surface go to the hit list,
-//                   records whose ray left the scene to the miss list (both per shard);
+//   classifyKernel  one lane per record of A: records whose ray hit a surface go to the hit list of
+//                   their shard; a record whose ray left the scene is finished on the spot
+//                   (environment, sample);
 //   shadeHitsKernel one lane per hit-list entry: the turn of the pathSample loop for a hit; a path
 //                   that goes on is written to the next free place of its shard's region of pool
 //                   B (dense, whole cache lines), a path that ends writes its sample;
-//   missKernel      one lane per miss-list entry: adds the environment, writes the sample;
-//   generateKernel  fills the rest of every region of B with new paths (path number by one atomic
-//                   per block, camera ray), or marks it empty when no paths are left.
+//   generateKernel  fills the rest of every region of B with new paths (the free places of a region
+//                   are one run, so path numbers need no reservation; camera ray), or marks it
+//                   empty when no paths are left.
 // Then B is traced.  Every wave of the heavy kernels is full of lanes doing the same kind of work,
 // records that need no shading are not loaded by the shading kernel, and all state stores are
 // dense.  New paths lie together in path-number order (neighbouring pixels), which also keeps the
 // camera rays of a wave and their first hits coherent.
-// (1024 threads per block: the two atomics per block are what bounds this kernel)
+// (1024 threads per block: the atomic per block is what bounds this kernel)
 constexpr uint32_t kClassifyBlock = 1024;
-__global__ void __launch_bounds__(kClassifyBlock) classifyKernel(Pool pool, uint32_t* __restrict__ counters)
+__global__ void __launch_bounds__(kClassifyBlock) classifyKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
+                                                                 float* __restrict__ samples)
 {
     __shared__ uint32_t lds[2 * (kClassifyBlock / 64 + 1)];
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
     const uint32_t slot = blockIdx.x * kClassifyBlock + threadIdx.x; // the grid covers the records exactly
     const uint8_t cls = pool.cls[slot];
-    const bool hit = cls == kClsHit, miss = cls == kClsMiss;
+    const bool hit = cls == kClsHit;
     const uint32_t shard = blockIdx.x % kShards;
-    uint32_t posH, posM;
+    uint32_t posH, unused;
     blockReserve2<kClassifyBlock / 64>(&counters[(kCtrHit + shard) * kCtrStride], hit,
-                                       &counters[(kCtrFree + shard) * kCtrStride], miss, lds, posH, posM);
+                                       &counters[(kCtrHit + shard) * kCtrStride], false, lds, posH, unused);
     if (hit)
         pool.hitList[size_t(shard) * pool.listCap + posH] = slot;
-    if (miss)
-        pool.freeList[size_t(shard) * pool.listCap + posM] = slot;
+    if (cls == kClsMiss) {
+        // the ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
+        const float4 rad_p = pool.rad_p[slot];
+        V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
+        if (sc.envmap.type != PT_ENV_NONE) {
+            const float4 thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
+            radiance = radiance + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
+        }
+        float* p = samples + 3 * size_t(fbits(rad_p.w));
+        p[0] = radiance.x;
+        p[1] = radiance.y;
+        p[2] = radiance.z;
+    }
 }
 
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
@@ -860,33 +875,6 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
     }
 }
 
-// paths whose ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
-__global__ void __launch_bounds__(256) missKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
-                                                  float* __restrict__ samples)
-{
-    // path numbers for generateKernel, which follows: it fills what the continuing paths leave free of
-    // every region of the other pool (nobody else touches these counters in between)
-    if (blockIdx.x == 0 && threadIdx.x < kShards)
-        counters[threadIdx.x * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + threadIdx.x) * kCtrStride];
-    const uint32_t first = blockIdx.x * 256u;
-    const uint32_t shard = first / pool.listCap;
-    const uint32_t fill = counters[(kCtrFree + shard) * kCtrStride];
-    const uint32_t entry = first - shard * pool.listCap + threadIdx.x;
-    if (entry >= fill)
-        return;
-    const uint32_t slot = pool.freeList[size_t(shard) * pool.listCap + entry];
-    const float4 rad_p = pool.rad_p[slot];
-    V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
-    if (sc.envmap.type != PT_ENV_NONE) {
-        const float4 thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
-        radiance = radiance + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
-    }
-    float* p = samples + 3 * size_t(fbits(rad_p.w));
-    p[0] = radiance.x;
-    p[1] = radiance.y;
-    p[2] = radiance.z;
-}
-
 // `next` = the pool being filled: the places of every region behind the paths that go on
 __global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, Batch b, uint32_t* __restrict__ counters)
 {
@@ -897,10 +885,10 @@ __global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, B
     const uint32_t inRegion = first - shard * regionCap + threadIdx.x;
     if (inRegion < goingOn)
         return; // a path that goes on
-    // the free places of a region are one run, so their path numbers need no reservation: missKernel
-    // has advanced the shard's counter past this launch's numbers already
+    // the free places of a region are one run, so their path numbers need no reservation; the next
+    // tracing launch moves the shard's counter on
     const uint32_t place = first + threadIdx.x;
-    const uint32_t local = counters[shard * kCtrStride] - (regionCap - inRegion);
+    const uint32_t local = counters[shard * kCtrStride] + (inRegion - goingOn);
     // shard q owns the groups of 64 path numbers g with g % kShards == q
     const uint32_t group = (local >> 6) * kShards + shard, inTile = local & 63u;
     // path number -> (8x8 tile, sample, pixel in tile): 64 consecutive numbers are one tile at one sample
@@ -992,7 +980,7 @@ uint32_t retryCapOf(uint32_t nSlots)
 
 size_t poolBytes(uint32_t n)
 {
-    return 2 * size_t(n) * (16 * 5 + 8 + 1) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 8)
+    return 2 * size_t(n) * (16 * 5 + 8 + 1) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 4)
         + size_t(retryCapOf(n)) * kRetryShards * 8;
 }
 
@@ -1015,7 +1003,6 @@ void carvePools(void* base, uint32_t n, Pool pools[2])
     p.retry = static_cast<uint2*>(take(size_t(p.retryCap) * kRetryShards * 8));
     p.listCap = shadowCapOf(n);
     p.hitList = static_cast<uint32_t*>(take(q * 4));
-    p.freeList = static_cast<uint32_t*>(take(q * 4));
     p.nSlots = n;
     for (int k = 0; k < 2; k++) {
         p.o_t = static_cast<float4*>(take(size_t(n) * 16));
@@ -1126,7 +1113,11 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
         && std::getenv("PT_NO_LDS_SCENE") == nullptr;
     const uint32_t shadowCap = shadowCapOf(nSlots);
-    const dim3 gridLists(pools[0].listCap / 256u * kShards), gridSlots(nSlots / 256u), block(256);
+    const dim3 gridSlots(nSlots / 256u), block(256);
+    // the first tracing launch has no generateKernel before it: nothing to add to the path numbers
+    for (uint32_t q = 0; q < kShards; q++)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrLive + q) * kCtrStride),
+                                  int(nSlots / kShards), 1, stream));
     bool exhaustedBefore = false; // every path number had been handed out at the previous check already
     uint64_t iter = 0;
     for (;;) {
@@ -1136,14 +1127,12 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             const Pool& next = pools[(iter + 1) & 1];
             launchTraceFor(sc, cur, stream, parity, dyn, lds);
             sc->kt.begin(KernelTimes::kClassify, stream);
-            hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyBlock), dim3(kClassifyBlock), 0, stream, cur, w.counters);
+            hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyBlock), dim3(kClassifyBlock), 0, stream, sc->dev, cur,
+                               w.counters, w.samples);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
             hipLaunchKernelGGL(shadeHitsKernel, dim3(pools[0].listCap / kShadeBlock * kShards), dim3(kShadeBlock), 0, stream,
                                sc->dev, cur, next, a.pp, w.counters, parity, w.samples, shadowCap);
-            sc->kt.end(stream);
-            sc->kt.begin(KernelTimes::kMiss, stream);
-            hipLaunchKernelGGL(missKernel, gridLists, block, 0, stream, sc->dev, cur, w.counters, w.samples);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kGenerate, stream);
             hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, next, a, b, w.counters);
@@ -1153,14 +1142,16 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
         HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         sc->kt.collect();
-        // finished when no path was alive in the last iteration and every path number had been
-        // handed out well before it (so that its generateKernel cannot have started one)
+        // finished when the last iteration shaded nothing and every path number had been handed out
+        // well before it (so that its generateKernel cannot have started a path)
         uint64_t alive = 0;
         bool exhausted = true;
+        const uint32_t regionCap = nSlots / kShards;
         for (uint32_t q = 0; q < kShards; q++) {
-            alive += w.hostCounters[(kCtrHit + q) * kCtrStride] + w.hostCounters[(kCtrFree + q) * kCtrStride]
-                + w.hostCounters[(kCtrLive + q) * kCtrStride];
-            const uint64_t handedOut = w.hostCounters[q * kCtrStride]; // path numbers of shard q
+            const uint32_t goingOn = w.hostCounters[(kCtrLive + q) * kCtrStride];
+            alive += w.hostCounters[(kCtrHit + q) * kCtrStride] + goingOn;
+            // path numbers of shard q: the counter as of the last tracing launch + the last generateKernel's
+            const uint64_t handedOut = uint64_t(w.hostCounters[q * kCtrStride]) + (regionCap - goingOn);
             if ((handedOut >> 6) * kShards + q < (b.totalIds >> 6))
                 exhausted = false;
         }
