@@ -629,13 +629,17 @@ PT_DEV void traverseStep(const DevScene& sc, const float4* __restrict__ nodes, c
 // The node half of a step: test node `cur` and move on; if it is a leaf whose box is hit,
 // report its surface in `pendingLeaf` (the caller must run the surface test -- which may
 // lower amax -- before the next node step, as the reference does).
+// (PIN: the table is in memory; the two loads are then kept whole, which the compiler does by itself for LDS)
+template <bool PIN>
 PT_DEV void nodeStep(const float4* __restrict__ nodes, const Ray& ray, float amin, float amax, uint32_t& cur,
                      uint32_t& pendingLeaf)
 {
     float4 n0 = nodes[2 * cur + 0];
     float4 n1 = nodes[2 * cur + 1];
-    keepWhole(n0);
-    keepWhole(n1);
+    if (PIN) {
+        keepWhole(n0);
+        keepWhole(n1);
+    }
     const uint32_t escape = fbits(n1.z);
     const uint32_t leaf = fbits(n1.w);
     const bool hit = aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax);

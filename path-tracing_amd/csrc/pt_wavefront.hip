@@ -206,9 +206,6 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #ifndef PT_WALK_LANES
 #define PT_WALK_LANES 24
 #endif
-#ifndef PT_WALK_UNROLL
-#define PT_WALK_UNROLL 2
-#endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
@@ -324,18 +321,12 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
             bool walking = have && pending == kInner && cur < sc.n_nodes;
             while (__builtin_amdgcn_ballot_w64(walking) != 0) {
                 if (walking)
-                    nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
+                    nodeStep<!LDS>(nodes, ray, 0.0001f, amax, cur, pending);
                 walking = have && pending == kInner && cur < sc.n_nodes;
-#if PT_WALK_UNROLL >= 2
+                // (two steps per vote: the votes and branches cost more than the lanes idling in the second)
                 if (walking)
-                    nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
+                    nodeStep<!LDS>(nodes, ray, 0.0001f, amax, cur, pending);
                 walking = have && pending == kInner && cur < sc.n_nodes;
-#endif
-#if PT_WALK_UNROLL >= 3
-                if (walking)
-                    nodeStep(nodes, ray, 0.0001f, amax, cur, pending);
-                walking = have && pending == kInner && cur < sc.n_nodes;
-#endif
                 if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
                     break;
             }
