@@ -371,74 +371,31 @@ struct HitLite {
     bool backside;
 };
 
-// AABB::hit, reference src/15/aabb.hpp:41-60.  NaN comparisons are false,
-// exactly as in the reference: a NaN slab neither rejects nor tightens.  The
-// reference returns at the first rejecting axis; evaluating all three axes and
-// combining the verdicts gives the same answer without branches.
-PT_DEV bool aabbHit(V3 lo, V3 hi, const Ray& ray, float amin, float amax)
-{
-    bool reject;
-    {
-        float inv = ray.invDirection.x, org = ray.origin.x;
-        bool neg = inv < 0.0f;
-        float admin = ((neg ? hi.x : lo.x) - org) * inv;
-        float admax = ((neg ? lo.x : hi.x) - org) * inv;
-        reject = (admin > amax) | (amin > admax);
-        amin = admin > amin ? admin : amin;
-        amax = admax < amax ? admax : amax;
-    }
-    {
-        float inv = ray.invDirection.y, org = ray.origin.y;
-        bool neg = inv < 0.0f;
-        float admin = ((neg ? hi.y : lo.y) - org) * inv;
-        float admax = ((neg ? lo.y : hi.y) - org) * inv;
-        reject |= (admin > amax) | (amin > admax);
-        amin = admin > amin ? admin : amin;
-        amax = admax < amax ? admax : amax;
-    }
-    {
-        float inv = ray.invDirection.z, org = ray.origin.z;
-        bool neg = inv < 0.0f;
-        float admin = ((neg ? hi.z : lo.z) - org) * inv;
-        float admax = ((neg ? lo.z : hi.z) - org) * inv;
-        reject |= (admin > amax) | (amin > admax);
-    }
-    return !reject;
-}
-
-// The same test, also giving the distance at which the box is entered (the largest slab
-// entry, or amin; NaN slabs ignored as above).
+// AABB::hit, reference src/15/aabb.hpp:41-60, also giving the distance at which the box is
+// entered.  The reference takes the axes in turn: per axis the near and the far plane by the
+// sign of the inverse direction, reject if the entry lies beyond the smallest exit so far (amax
+// to begin with) or the exit before the largest entry so far (amin to begin with), else tighten
+// both; a NaN slab (0 * inf) compares false, so it neither rejects nor tightens.  Every entry
+// gets compared with every exit of an earlier axis and the other way round, and an axis's own
+// entry never exceeds its own exit (lo <= hi and rounding is monotone), so the verdict over the
+// three axes is: largest non-NaN entry > smallest non-NaN exit.  fmaxf/fminf return the other
+// operand when one is NaN, which is the reference's "not tightened".
 PT_DEV bool aabbEntry(V3 lo, V3 hi, const Ray& ray, float amin, float amax, float& entry)
 {
-    bool reject;
-    {
-        float inv = ray.invDirection.x, org = ray.origin.x;
-        bool neg = inv < 0.0f;
-        float admin = ((neg ? hi.x : lo.x) - org) * inv;
-        float admax = ((neg ? lo.x : hi.x) - org) * inv;
-        reject = (admin > amax) | (amin > admax);
-        amin = admin > amin ? admin : amin;
-        amax = admax < amax ? admax : amax;
-    }
-    {
-        float inv = ray.invDirection.y, org = ray.origin.y;
-        bool neg = inv < 0.0f;
-        float admin = ((neg ? hi.y : lo.y) - org) * inv;
-        float admax = ((neg ? lo.y : hi.y) - org) * inv;
-        reject |= (admin > amax) | (amin > admax);
-        amin = admin > amin ? admin : amin;
-        amax = admax < amax ? admax : amax;
-    }
-    {
-        float inv = ray.invDirection.z, org = ray.origin.z;
-        bool neg = inv < 0.0f;
-        float admin = ((neg ? hi.z : lo.z) - org) * inv;
-        float admax = ((neg ? lo.z : hi.z) - org) * inv;
-        reject |= (admin > amax) | (amin > admax);
-        amin = admin > amin ? admin : amin;
-    }
-    entry = amin;
-    return !reject;
+    const V3 inv = ray.invDirection, org = ray.origin;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const float inX = ((nx ? hi.x : lo.x) - org.x) * inv.x, outX = ((nx ? lo.x : hi.x) - org.x) * inv.x;
+    const float inY = ((ny ? hi.y : lo.y) - org.y) * inv.y, outY = ((ny ? lo.y : hi.y) - org.y) * inv.y;
+    const float inZ = ((nz ? hi.z : lo.z) - org.z) * inv.z, outZ = ((nz ? lo.z : hi.z) - org.z) * inv.z;
+    entry = fmaxf(fmaxf(fmaxf(inX, inY), inZ), amin);
+    const float exit = fminf(fminf(fminf(outX, outY), outZ), amax);
+    return !(entry > exit);
+}
+
+PT_DEV bool aabbHit(V3 lo, V3 hi, const Ray& ray, float amin, float amax)
+{
+    float entry;
+    return aabbEntry(lo, hi, ray, amin, amax, entry);
 }
 
 // keep a 16-byte record whole: stops the compiler from splitting the load into
