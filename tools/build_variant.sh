@@ -6,7 +6,7 @@ name=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT/path-tracing_amd/csrc"
 mkdir -p ../lib/variants /tmp/ptv_$name
-FLAGS="-std=c++17 -O3 -ffp-contract=off -fPIC -I../../include -I. $*"
+FLAGS="-std=c++17 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -I../../include -I. $*"
 /opt/rocm/bin/hipcc $FLAGS --offload-arch=gfx950 -c pt_wavefront.hip -o /tmp/ptv_$name/pt_wavefront.o &
 /opt/rocm/bin/hipcc $FLAGS --offload-arch=gfx950 -c pt_kernels.hip -o /tmp/ptv_$name/pt_kernels.o &
 wait
