@@ -201,13 +201,14 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #define PT_ITEMS_PER_LANE 8
 #endif
 #ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 16
+#define PT_REFILL_LANES 32
 #endif
 #ifndef PT_WALK_LANES
 #define PT_WALK_LANES 24
 #endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
+constexpr uint32_t kRefillLanesOrdered = 16;      // the same for traceOrderedKernel
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
 template <bool DYN, bool LDS>
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
         const uint32_t nIdle = uint32_t(__popcll(idle));
         if (nIdle == 64u && pos >= endPos)
             break;
-        if (pos < endPos && (nIdle >= kRefillLanes || nIdle == 64u)) {
+        if (pos < endPos && (nIdle >= kRefillLanesOrdered || nIdle == 64u)) {
             const uint32_t cand = pos + uint32_t(__popcll(idle & below));
             if (!have && cand < endPos) {
                 item = cand;
@@ -666,7 +667,7 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
 }
 
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4
+#define PT_SHADE_WAVES 5
 #endif
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 256
