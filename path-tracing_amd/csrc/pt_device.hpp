@@ -22,6 +22,7 @@ using namespace ptv;
 
 constexpr uint32_t kInner = 0xFFFFFFFFu; // "no surface": a node step that did not end on a hit leaf
 constexpr uint32_t kInnerBit = 0x80000000u; // DevNode.leaf of an inner node: kInnerBit | index of its second child
+constexpr uint32_t kLeafRowBit = 0x40000000u; // in a link of the `wide` table, see DevScene
 
 // surface kinds (SurfRec word 3 of row 0)
 enum : uint32_t {
@@ -53,8 +54,14 @@ struct DevMesh {
 // texture -> value).
 struct DevScene {
     const float4* nodes;
-    const float4* wide;      // per inner node 4 x float4: boxes of both children (lo1.xyz hi1.x | hi1.yz lo2.xy |
-                             // lo2.z hi2.xyz) and their leaf fields (surface id, or kInnerBit | node number)
+    const uint4* wide;       // per inner node (numbered in storage order, inner nodes only) 2 x uint4: the boxes of
+                             // both children on a 16-bit grid over the root box, rounded outwards (6 words:
+                             // lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16 for the first child, the
+                             // same for the second), then the links of the two children: kInnerBit | inner
+                             // number, or a static triangle's surface id (its box is that of its vertices), or
+                             // kLeafRowBit | node number (box and surface are in that row of `nodes`).  Null
+                             // if the boxes do not fit the grid (non-finite coordinates).
+    float qbase[3], qstep[3]; // grid coordinate q of axis a stands for fmaf(q, qstep[a], qbase[a])
     const float4* surf;
     const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24);
                              // spheres (sphere index, 0, 0, material | flags << 24).  flags: 1 normals,

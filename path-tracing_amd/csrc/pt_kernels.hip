@@ -11,8 +11,11 @@
 //   traceRaysKernel      one lane per caller-supplied ray
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -190,25 +193,112 @@ int buildDeviceNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& 
     return PT_OK;
 }
 
-// Per inner node k, one 64-byte row with what a step of the nearer-child-first walk needs:
-// the boxes of both children and their leaf fields (surface id, or kInnerBit | node number).
-// Rows of leaf nodes are unused.
-void buildWideNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& out)
+// The table of the nearer-child-first walk: per inner node (numbered in storage order among the
+// inner nodes) one 32-byte row with the boxes of both children on a 16-bit grid over the root
+// box and the children's links (see DevScene::wide).  A grid box always contains the exact one:
+// the corner values are checked with the very expression the device decodes them with.  The
+// walk uses grid boxes only to skip and to order subtrees; whether a surface is tested, and the
+// entry distance that goes into the rule for when a result stands, come from the leaf's exact
+// box -- that of a static triangle's vertices where the two agree bit for bit (checked here),
+// else the leaf's row of `nodes`.
+// Returns false if the boxes cannot be put on a grid (non-finite, or outside the root box).
+bool buildWideNodes(const pt_bvh_node* nodes, uint64_t n, const std::vector<float4>& surf, std::vector<uint4>& out,
+                    float base[3], float step[3])
 {
-    out.assign(4 * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    auto leafField = [&](uint64_t c) {
-        return (nodes[c].link % 2 == 0) ? uint32_t(nodes[c].link / 2) : (kInnerBit | uint32_t(c));
+    out.clear();
+    for (int a = 0; a < 3; a++) {
+        base[a] = 0.0f;
+        step[a] = 1.0f;
+    }
+    if (n == 0)
+        return true;
+    if (n >= kLeafRowBit)
+        return false;
+    for (int a = 0; a < 3; a++) {
+        const float lo = nodes[0].lo[a], hi = nodes[0].hi[a];
+        if (!std::isfinite(lo) || !std::isfinite(hi) || !(lo <= hi))
+            return false;
+        base[a] = lo;
+        float st = (hi - lo) / 65535.0f;
+        if (!std::isfinite(st))
+            return false;
+        if (!(st > 1.0e-30f))
+            st = 1.0e-30f;
+        for (int guard = 0; guard < 64 && std::fmaf(65535.0f, st, lo) < hi; guard++)
+            st = std::nextafterf(st, std::numeric_limits<float>::infinity());
+        if (std::fmaf(65535.0f, st, lo) < hi)
+            return false;
+        step[a] = st;
+    }
+    // grid coordinate at or below / at or above a value
+    auto below = [&](int a, float v, uint32_t& q) {
+        if (!std::isfinite(v) || v < base[a])
+            return false;
+        double est = std::floor((double(v) - double(base[a])) / double(step[a]));
+        int64_t k = int64_t(std::min(std::max(est, 0.0), 65535.0));
+        while (k > 0 && std::fmaf(float(k), step[a], base[a]) > v)
+            k--;
+        while (k < 65535 && std::fmaf(float(k + 1), step[a], base[a]) <= v)
+            k++;
+        if (std::fmaf(float(k), step[a], base[a]) > v)
+            return false;
+        q = uint32_t(k);
+        return true;
     };
+    auto above = [&](int a, float v, uint32_t& q) {
+        if (!std::isfinite(v))
+            return false;
+        double est = std::ceil((double(v) - double(base[a])) / double(step[a]));
+        int64_t k = int64_t(std::min(std::max(est, 0.0), 65535.0));
+        while (k < 65535 && std::fmaf(float(k), step[a], base[a]) < v)
+            k++;
+        while (k > 0 && std::fmaf(float(k - 1), step[a], base[a]) >= v)
+            k--;
+        if (std::fmaf(float(k), step[a], base[a]) < v)
+            return false;
+        q = uint32_t(k);
+        return true;
+    };
+    std::vector<uint32_t> innerNumber(n, 0);
+    uint32_t nInner = 0;
+    for (uint64_t k = 0; k < n; k++)
+        if (nodes[k].link % 2 == 1)
+            innerNumber[k] = nInner++;
+    auto linkOf = [&](uint64_t c) -> uint32_t {
+        if (nodes[c].link % 2 == 1)
+            return kInnerBit | innerNumber[c];
+        const uint64_t sid = nodes[c].link / 2;
+        if (3 * sid + 2 < surf.size() && __builtin_bit_cast(uint32_t, surf[3 * sid].w) == kTriStatic) {
+            const float4 &A = surf[3 * sid], &B = surf[3 * sid + 1], &C = surf[3 * sid + 2];
+            const float lo[3] = { std::min(A.x, std::min(B.x, C.x)), std::min(A.y, std::min(B.y, C.y)),
+                                  std::min(A.z, std::min(B.z, C.z)) };
+            const float hi[3] = { std::max(A.x, std::max(B.x, C.x)), std::max(A.y, std::max(B.y, C.y)),
+                                  std::max(A.z, std::max(B.z, C.z)) };
+            if (std::memcmp(lo, nodes[c].lo, 12) == 0 && std::memcmp(hi, nodes[c].hi, 12) == 0)
+                return uint32_t(sid);
+        }
+        return kLeafRowBit | uint32_t(c);
+    };
+    out.assign(2 * size_t(nInner), make_uint4(0, 0, 0, 0));
     for (uint64_t k = 0; k < n; k++) {
         if (nodes[k].link % 2 == 0)
             continue;
-        const uint64_t c1 = k + 1, c2 = nodes[k].link / 2;
-        const pt_bvh_node &a = nodes[c1], &b = nodes[c2];
-        out[4 * k + 0] = make_float4(a.lo[0], a.lo[1], a.lo[2], a.hi[0]);
-        out[4 * k + 1] = make_float4(a.hi[1], a.hi[2], b.lo[0], b.lo[1]);
-        out[4 * k + 2] = make_float4(b.lo[2], b.hi[0], b.hi[1], b.hi[2]);
-        out[4 * k + 3] = make_float4(__builtin_bit_cast(float, leafField(c1)), __builtin_bit_cast(float, leafField(c2)), 0.0f, 0.0f);
+        const uint64_t child[2] = { k + 1, nodes[k].link / 2 };
+        uint32_t w[6];
+        for (int c = 0; c < 2; c++) {
+            uint32_t qlo[3], qhi[3];
+            for (int a = 0; a < 3; a++)
+                if (!below(a, nodes[child[c]].lo[a], qlo[a]) || !above(a, nodes[child[c]].hi[a], qhi[a]))
+                    return false;
+            w[3 * c + 0] = qlo[0] | (qlo[1] << 16);
+            w[3 * c + 1] = qlo[2] | (qhi[0] << 16);
+            w[3 * c + 2] = qhi[1] | (qhi[2] << 16);
+        }
+        const size_t r = 2 * size_t(innerNumber[k]);
+        out[r + 0] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[r + 1] = make_uint4(w[4], w[5], linkOf(child[0]), linkOf(child[1]));
     }
+    return true;
 }
 
 int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_params* p, const void* out, RenderArgs& a)
@@ -327,8 +417,6 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     rc = buildDeviceNodes(d->bvh_nodes, d->n_bvh_nodes, nodes);
     if (rc != PT_OK)
         return rc;
-    std::vector<float4> wide;
-    buildWideNodes(d->bvh_nodes, d->n_bvh_nodes, wide);
 
     std::vector<DevMesh> meshes(d->n_meshes);
     for (uint64_t i = 0; i < d->n_meshes; i++) {
@@ -430,7 +518,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
         return code;
     };
     float4* dNodes = nullptr;
-    float4* dWide = nullptr;
+    uint4* dWide = nullptr;
     float4* dSurf = nullptr;
     uint4* dSurfAttr = nullptr;
     float4* dMatConst = nullptr;
@@ -442,7 +530,12 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     pt_texture* dTex = nullptr;
     pt_animation* dAnims = nullptr;
     if ((rc = upload(nodes.data(), nodes.size(), &dNodes, sc->owned)) != PT_OK) return bail(rc);
+    // (room for a row per inner node even if this tree's boxes do not fit the grid: a later tree's may)
+    std::vector<uint4> wide;
+    const bool haveWide = buildWideNodes(d->bvh_nodes, d->n_bvh_nodes, surf, wide, dev.qbase, dev.qstep);
+    wide.resize(2 * size_t(d->n_surfaces > 0 ? d->n_surfaces - 1 : 0), make_uint4(0, 0, 0, 0));
     if ((rc = upload(wide.data(), wide.size(), &dWide, sc->owned)) != PT_OK) return bail(rc);
+    sc->hostSurf = surf;
     if ((rc = upload(surf.data(), surf.size(), &dSurf, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(surfAttr.data(), surfAttr.size(), &dSurfAttr, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(matConst.data(), matConst.size(), &dMatConst, sc->owned)) != PT_OK) return bail(rc);
@@ -461,7 +554,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     sc->nodes = dNodes;
     sc->wide = dWide;
     dev.nodes = dNodes;
-    dev.wide = dWide;
+    dev.wide = haveWide ? dWide : nullptr;
     dev.surf = dSurf;
     dev.surfAttr = dSurfAttr;
     dev.matConst = dMatConst;
@@ -507,8 +600,14 @@ int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_no
     DeviceGuard g(scene->device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(scene->nodes, dn.data(), dn.size() * sizeof(float4), hipMemcpyHostToDevice));
-    buildWideNodes(nodes, n_nodes, dn);
-    HIP_TRY(hipMemcpy(scene->wide, dn.data(), dn.size() * sizeof(float4), hipMemcpyHostToDevice));
+    std::vector<uint4> wide;
+    if (buildWideNodes(nodes, n_nodes, scene->hostSurf, wide, scene->dev.qbase, scene->dev.qstep)) {
+        if (!wide.empty())
+            HIP_TRY(hipMemcpy(scene->wide, wide.data(), wide.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        scene->dev.wide = scene->wide;
+    } else {
+        scene->dev.wide = nullptr;
+    }
     return PT_OK;
 }
 

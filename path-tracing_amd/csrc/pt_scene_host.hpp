@@ -141,7 +141,8 @@ struct pt_scene {
     ptd::DevScene dev;
     std::vector<void*> owned; // every device allocation of the scene
     float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
-    float4* wide = nullptr;   // likewise
+    uint4* wide = nullptr;    // likewise (room for n_surfaces - 1 rows)
+    std::vector<float4> hostSurf; // the surface table as uploaded: which leaves have the box of their vertices
     uint64_t n_surfaces = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;

@@ -208,7 +208,14 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
-constexpr uint32_t kRefillLanesOrdered = 16;      // the same for traceOrderedKernel
+#ifndef PT_REFILL_LANES_ORDERED
+#define PT_REFILL_LANES_ORDERED 16
+#endif
+#ifndef PT_WALK_LANES_ORDERED
+#define PT_WALK_LANES_ORDERED 32
+#endif
+constexpr uint32_t kRefillLanesOrdered = PT_REFILL_LANES_ORDERED; // the same for traceOrderedKernel
+constexpr uint32_t kWalkLanesOrdered = PT_WALK_LANES_ORDERED;
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
 template <bool DYN, bool LDS>
@@ -367,17 +374,27 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
 // order by traceRetryKernel; so is a ray that had to leave out a subtree for lack of stack,
 // unless that subtree is entered beyond the limit.
 //
-// Per lane: the node it stands on, as its leaf field `link` (a surface, or kInnerBit | node
-// number; its box is known to be hit), `gate` = the largest entry distance on the way down,
-// and a stack of (link, gate) in LDS.  A step at an inner node reads one 64-byte row with
-// the boxes and leaf fields of both children.
+// Per lane: the node it stands on, as its `link` (see DevScene::wide), `gate` = the largest
+// entry distance on the way down, and a stack of (link, gate) in LDS.  A step at an inner node
+// reads one 32-byte row with the boxes of both children on a 16-bit grid, rounded outwards, and
+// their links: half the bytes of exact boxes, and the kernel runs at what HBM delivers.  Grid
+// boxes are entered no later than the exact ones, so they may be used to skip and to order
+// subtrees (and for the stack-overflow rule, which errs towards a second pass).  The entry
+// distance that the rule above needs is the exact one of the boxes above the surface; entry
+// distances grow from a box to a box inside it, so that of the leaf's own exact box is the
+// largest of them.  A leaf step therefore tests the exact box first (as the reference does) --
+// computed from the vertices of a static triangle, read from the leaf's row of `nodes`
+// otherwise -- and takes its entry distance as the gate.
 #ifndef PT_STACK_DEPTH
 #define PT_STACK_DEPTH 12
 #endif
 constexpr uint32_t kStackDepth = PT_STACK_DEPTH;
 constexpr float kTieBand = 1.0e-4f;
 
-constexpr uint32_t kRetryBuf = 128;
+#ifndef PT_RETRY_BUF
+#define PT_RETRY_BUF 64
+#endif
+constexpr uint32_t kRetryBuf = PT_RETRY_BUF;
 
 // Move a wave's buffered retry entries to its sub-list of the retry list: one atomic per call.
 PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx, const uint2* buf, uint32_t n)
@@ -396,7 +413,7 @@ PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx,
 }
 
 #ifndef PT_ORDERED_WAVES
-#define PT_ORDERED_WAVES 1
+#define PT_ORDERED_WAVES 6
 #endif
 template <bool DYN>
 __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
@@ -415,7 +432,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
             counters[(kCtrLive + q) * kCtrStride] = 0;
         }
     const float4* __restrict__ nodes = sc.nodes;
-    const float4* __restrict__ wide = sc.wide;
+    const uint4* __restrict__ wide = sc.wide;
     const float4* __restrict__ surf = sc.surf;
     const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
@@ -483,7 +500,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                         const float4 n0 = nodes[0], n1 = nodes[1];
                         if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, gate)) {
                             walkOver = false;
-                            link = (fbits(n1.w) & kInnerBit) ? kInnerBit : fbits(n1.w); // inner root = node 0
+                            link = (fbits(n1.w) & kInnerBit) ? kInnerBit : kLeafRowBit; // inner number 0, or node 0
                         }
                     }
                 }
@@ -497,19 +514,24 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
             while (__builtin_amdgcn_ballot_w64(walking) != 0) {
                 if (walking) {
                     const uint32_t k = link & ~kInnerBit;
-                    float4 w0 = wide[4 * k + 0], w1 = wide[4 * k + 1], w2 = wide[4 * k + 2], w3 = wide[4 * k + 3];
-                    keepWhole(w0);
-                    keepWhole(w1);
-                    keepWhole(w2);
-                    keepWhole(w3);
+                    const uint4 q0 = wide[2 * k + 0], q1 = wide[2 * k + 1];
+                    const V3 base = v3(sc.qbase[0], sc.qbase[1], sc.qbase[2]), step = v3(sc.qstep[0], sc.qstep[1], sc.qstep[2]);
+                    const V3 lo1 = v3(fmaf(float(q0.x & 0xFFFFu), step.x, base.x), fmaf(float(q0.x >> 16), step.y, base.y),
+                                      fmaf(float(q0.y & 0xFFFFu), step.z, base.z));
+                    const V3 hi1 = v3(fmaf(float(q0.y >> 16), step.x, base.x), fmaf(float(q0.z & 0xFFFFu), step.y, base.y),
+                                      fmaf(float(q0.z >> 16), step.z, base.z));
+                    const V3 lo2 = v3(fmaf(float(q0.w & 0xFFFFu), step.x, base.x), fmaf(float(q0.w >> 16), step.y, base.y),
+                                      fmaf(float(q1.x & 0xFFFFu), step.z, base.z));
+                    const V3 hi2 = v3(fmaf(float(q1.x >> 16), step.x, base.x), fmaf(float(q1.y & 0xFFFFu), step.y, base.y),
+                                      fmaf(float(q1.y >> 16), step.z, base.z));
                     float e1, e2;
-                    const bool h1 = aabbEntry(v3(w0.x, w0.y, w0.z), v3(w0.w, w1.x, w1.y), ray, 0.0001f, cull, e1);
-                    const bool h2 = aabbEntry(v3(w1.z, w1.w, w2.x), v3(w2.y, w2.z, w2.w), ray, 0.0001f, cull, e2);
+                    const bool h1 = aabbEntry(lo1, hi1, ray, 0.0001f, cull, e1);
+                    const bool h2 = aabbEntry(lo2, hi2, ray, 0.0001f, cull, e2);
                     const float g1 = fmaxf(gate, e1), g2 = fmaxf(gate, e2);
                     const bool firstNear = e1 <= e2;
                     if (h1 && h2) {
                         if (top < kStackDepth) {
-                            stack[top][threadIdx.x] = make_uint2(fbits(firstNear ? w3.y : w3.x), fbits(firstNear ? g2 : g1));
+                            stack[top][threadIdx.x] = make_uint2(firstNear ? q1.w : q1.z, fbits(firstNear ? g2 : g1));
                             top++;
                         } else {
                             // no room: leave the farther subtree out; the result stands if it turns
@@ -520,7 +542,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                     const bool take1 = h1 && (!h2 || firstNear);
                     if (h1 || h2) {
                         gate = take1 ? g1 : g2;
-                        link = fbits(take1 ? w3.x : w3.y);
+                        link = take1 ? q1.z : q1.w;
                     } else {
                         walkOver = true; // nothing below: take the next kept node
                     }
@@ -539,14 +561,44 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                     }
                 }
                 walking = have && !walkOver && (link & kInnerBit);
-                if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
+                if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanesOrdered)
                     break;
             }
         }
         // leaves: test the surface, then take the next kept node
         if (have && !walkOver && !(link & kInnerBit)) {
             HitLite h;
-            if (surfaceTest<DYN>(sc, surf, link, ray, 0.0001f, cull, h)) {
+            bool found = false;
+            if (link & kLeafRowBit) {
+                const uint32_t k = link & ~kLeafRowBit;
+                const float4 n0 = nodes[2 * k + 0], n1 = nodes[2 * k + 1];
+                float e;
+                if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, e)) {
+                    gate = e;
+                    found = surfaceTest<DYN>(sc, surf, fbits(n1.w), ray, 0.0001f, cull, h);
+                }
+            } else {
+                // a static triangle: its box is that of its vertices (reference src/15/surface_triangle.hpp:44-45)
+                const float4 r0 = surf[3 * link + 0], r1 = surf[3 * link + 1], r2 = surf[3 * link + 2];
+                const V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
+                const V3 lo = v3(fminf(A.x, fminf(B.x, C.x)), fminf(A.y, fminf(B.y, C.y)), fminf(A.z, fminf(B.z, C.z)));
+                const V3 hi = v3(fmaxf(A.x, fmaxf(B.x, C.x)), fmaxf(A.y, fmaxf(B.y, C.y)), fmaxf(A.z, fmaxf(B.z, C.z)));
+                float e;
+                if (aabbEntry(lo, hi, ray, 0.0001f, cull, e)) {
+                    gate = e;
+                    float a, u, v;
+                    bool bs;
+                    if (triTest(A, B, C, ray, 0.0001f, cull, a, u, v, bs)) {
+                        h.sid = link;
+                        h.a = a;
+                        h.u = u;
+                        h.v = v;
+                        h.backside = bs;
+                        found = true;
+                    }
+                }
+            }
+            if (found) {
                 if (best.sid == PT_NO_HIT || h.a < best.a) {
                     if (best.sid != PT_NO_HIT)
                         otherT = fminf(otherT, best.a);
@@ -1061,7 +1113,7 @@ void launchTrace(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity)
     const char* traversal = std::getenv("PT_TRAVERSAL");
     const bool referenceOrder = traversal && std::strcmp(traversal, "reference") == 0;
     // (for scenes held in LDS the storage-order walk is the faster one: measured 353 against 610 us per launch)
-    const bool ordered = !LDS && !referenceOrder;
+    const bool ordered = !LDS && !referenceOrder && sc->dev.wide != nullptr;
     sc->kt.begin(KernelTimes::kTrace, stream);
     if (ordered) {
         hipLaunchKernelGGL((traceOrderedKernel<DYN>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity,
