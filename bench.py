@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sqrt-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bvh", choices=["host", "device"], default="host",
+                    help="host: the reference's tree (pt_bvh_build); device: the tree built by pt_scene_build_bvh_device")
     args = ap.parse_args()
 
     import torch
@@ -179,6 +181,14 @@ def main():
     frames = extra.get("frames")
     mode = extra.get("sharding", "batches")
     dev = pt.DeviceScene(scene, device=local_rank)
+    bvh_build_ms = None
+    if args.bvh == "device":
+        dev.build_bvh_device(0.0, 0.0)  # first call allocates the work area
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        dev.build_bvh_device(0.0, 0.0)
+        torch.cuda.synchronize()
+        bvh_build_ms = (time.perf_counter() - tb) * 1e3
     out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     # every rank renders its own batch of samples of the same frame (its own seed)
@@ -200,7 +210,10 @@ def main():
             # upload, render; no exchange
             for f in shard.plan_frames(len(frames), world, rank):
                 t0f, t1f = frames[f]
-                dev.update_bvh(scene.build_bvh(t0f, t1f))
+                if args.bvh == "device":
+                    dev.build_bvh_device(t0f, t1f, stream.cuda_stream)
+                else:
+                    dev.update_bvh(scene.build_bvh(t0f, t1f))
                 render(pt.make_params(W, H, sqrt_spp, seed=42 + f, t0=t0f, t1=t1f, samples=samples), out)
         elif world == 1:
             render(params, out)
@@ -288,7 +301,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if mode == "batches" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label, "width": W, "height": H, "spp": spp,
+            "config": {"workload": label, "width": W, "height": H, "spp": spp, "bvh": args.bvh, "bvh_build_ms": bvh_build_ms,
                        "samples_per_step": total_samples / args.steps,
                        "sharding": "single GPU" if world == 1 else
                        {"batches": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp,

@@ -328,6 +328,21 @@ int pt_image_to_8bit_device(int device, const float* d_rgb, int width, int heigh
 int pt_image_to_8bit(int device, const float* rgb, int width, int height, float urq_max_val, float urq_brightness,
                      int flip_rows, unsigned char* out);
 
+/* The acceleration structure built on the device for the time interval
+ * [t0, t1] and installed in the scene: what BVHNode::buildBVH +
+ * BVHTreeLinear::flattenBVH produce on one host thread (reference
+ * src/15/bvh.hpp:36-108,146-176) and src/07/pathtracer-frames.cpp:209-211
+ * repeats per frame.  Surface bounds are the reference's (Surface::aabb,
+ * surface_triangle.hpp:32-63, surface_sphere.hpp:50-69); the tree is a
+ * Morton-order radix tree, not the reference's sorted-sweep tree, so rays
+ * find the same surface at the same distance except where two surfaces are
+ * hit at exactly equal distances (the walk order decides those).  A scene may
+ * be created with n_bvh_nodes == 0 and get its first tree here.
+ * pt_scene_get_bvh copies the installed tree out in the layout of
+ * pt_scene_desc.bvh_nodes (call with out_nodes == NULL to get the count). */
+int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_stream);
+int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity, uint64_t* out_count);
+
 /* ------------------------------------------------------- host-side helpers -- */
 
 /* Build the acceleration structure over [t0, t1] exactly as

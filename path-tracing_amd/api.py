@@ -55,6 +55,8 @@ def lib():
         L.pt_scene_desc_free.restype = None
         L.pt_scene_create.argtypes = [C.POINTER(abi.pt_scene_desc), C.c_int, C.POINTER(C.c_void_p)]
         L.pt_scene_update_bvh.argtypes = [C.c_void_p, C.POINTER(abi.pt_bvh_node), C.c_uint64]
+        L.pt_scene_build_bvh_device.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.pt_scene_get_bvh.argtypes = [C.c_void_p, C.POINTER(abi.pt_bvh_node), C.c_uint64, C.POINTER(C.c_uint64)]
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp]
         L.pt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params),
                                        C.c_void_p, C.c_void_p]
@@ -515,6 +517,18 @@ class DeviceScene:
     def update_bvh(self, nodes):
         nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
         _check(lib().pt_scene_update_bvh(self.handle, nodes.ctypes.data_as(C.POINTER(abi.pt_bvh_node)), len(nodes)))
+
+    def build_bvh_device(self, t0=0.0, t1=0.0, stream=None):
+        """Build the acceleration structure over [t0, t1] on the device and install it."""
+        _check(lib().pt_scene_build_bvh_device(self.handle, t0, t1, C.c_void_p(stream or 0)))
+
+    def get_bvh(self):
+        """The installed tree as an array of NODE_DTYPE in the layout of pt_scene_desc.bvh_nodes."""
+        n = C.c_uint64(0)
+        _check(lib().pt_scene_get_bvh(self.handle, None, 0, C.byref(n)))
+        nodes = np.zeros(n.value, NODE_DTYPE)
+        _check(lib().pt_scene_get_bvh(self.handle, nodes.ctypes.data_as(C.POINTER(abi.pt_bvh_node)), n.value, C.byref(n)))
+        return nodes
 
     def render(self, cam, params, out=None):
         """Host-buffer render: (height, width, 3) float32, row 0 = bottom."""

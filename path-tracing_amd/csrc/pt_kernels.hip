@@ -389,6 +389,8 @@ void pt_scene_destroy(pt_scene* scene)
     ptWavefrontRelease(scene);
     for (void* p : scene->owned)
         (void)hipFree(p);
+    if (scene->buildArea)
+        (void)hipFree(scene->buildArea);
     if (scene->evStart)
         (void)hipEventDestroy(scene->evStart);
     if (scene->evStop)
@@ -404,8 +406,9 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     int rc = pt_scene_desc_validate(d);
     if (rc != PT_OK)
         return rc;
-    if (d->n_surfaces == 0 || d->n_bvh_nodes != 2 * d->n_surfaces - 1)
-        return fail(PT_ERR_INVALID_ARGUMENT, "scene needs at least one surface and a built acceleration structure");
+    // (no nodes at all: the tree is to be built on the device, pt_scene_build_bvh_device, before the first render)
+    if (d->n_surfaces == 0 || (d->n_bvh_nodes != 0 && d->n_bvh_nodes != 2 * d->n_surfaces - 1))
+        return fail(PT_ERR_INVALID_ARGUMENT, "scene needs at least one surface and a built acceleration structure or none");
     if (device < 0 || device >= pt_device_count())
         return fail(PT_ERR_DEVICE, "no such GPU: " + std::to_string(device));
     DeviceGuard g(device);
@@ -414,9 +417,12 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
 
     // host-side preparation: device nodes, per-surface rows, mesh table
     std::vector<float4> nodes;
-    rc = buildDeviceNodes(d->bvh_nodes, d->n_bvh_nodes, nodes);
-    if (rc != PT_OK)
-        return rc;
+    if (d->n_bvh_nodes > 0) {
+        rc = buildDeviceNodes(d->bvh_nodes, d->n_bvh_nodes, nodes);
+        if (rc != PT_OK)
+            return rc;
+    }
+    nodes.resize(2 * (2 * size_t(d->n_surfaces) - 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f)); // room for any tree
 
     std::vector<DevMesh> meshes(d->n_meshes);
     for (uint64_t i = 0; i < d->n_meshes; i++) {

@@ -143,6 +143,8 @@ struct pt_scene {
     float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
     uint4* wide = nullptr;    // likewise (room for n_surfaces - 1 rows)
     std::vector<float4> hostSurf; // the surface table as uploaded: which leaves have the box of their vertices
+    void* buildArea = nullptr; // work area of pt_scene_build_bvh_device, kept between calls (not in owned)
+    size_t buildCapacity = 0;
     uint64_t n_surfaces = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
