@@ -33,13 +33,14 @@ static bool writeFile(const std::string& name, const void* data, size_t bytes)
 int main(int argc, char* argv[])
 {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s OUT_PREFIX [WIDTH HEIGHT SQRT_SPP]\n", argv[0]);
+        fprintf(stderr, "usage: %s OUT_PREFIX [WIDTH HEIGHT SQRT_SPP [devicebvh]]\n", argv[0]);
         return 2;
     }
     const std::string prefix = argv[1];
     const int width = argc > 2 ? atoi(argv[2]) : 96;
     const int height = argc > 3 ? atoi(argv[3]) : 64;
     const int sqrtSpp = argc > 4 ? atoi(argv[4]) : 3;
+    const bool deviceBvh = argc > 5 && std::string(argv[5]) == "devicebvh";
 
     Scene scene;
     // a floor: one textured quad under a constant pose
@@ -67,7 +68,9 @@ int main(int argc, char* argv[])
     Animation* camPose = scene.take(new AnimationConstant(Transformation(vec3(0.0f, 3.0f, 9.0f), vec3(0.0f, 1.0f, 0.0f))));
     Camera camera(radians(40.0f), float(width) / height, 9.0f, 0.2f, camPose);
 
-    scene.buildBVH(0.0f, 0.0f);
+    // (with `devicebvh` the tree is left to ptamd::render, which then builds it on the GPU)
+    if (!deviceBvh)
+        scene.buildBVH(0.0f, 0.0f);
 
     // was: the pixel loop of src/15/pathtracer.cpp:199-221
     std::string err;
@@ -84,6 +87,8 @@ int main(int argc, char* argv[])
     }
 
     // what the binding handed over, for the test to render with the oracle
+    if (deviceBvh)
+        scene.buildBVH(0.0f, 0.0f);
     ptio::SceneData flat;
     pt_camera cam;
     if (!ptamd::flattenScene(scene, flat, err) || !ptamd::flattenCamera(camera, cam, err)) {

@@ -464,6 +464,14 @@ inline std::vector<vec3> render(const Scene& scene, const Camera& camera, int wi
             *err = pt_last_error();
         return img;
     }
+    // a scene handed over before scene.buildBVH(t0, t1) gets its tree built on the GPU
+    // (the reference's builder is one host thread: seconds per million surfaces)
+    if (desc.n_bvh_nodes == 0 && pt_scene_build_bvh_device(dev, t0, t1, nullptr) != PT_OK) {
+        if (err)
+            *err = pt_last_error();
+        pt_scene_destroy(dev);
+        return img;
+    }
     pt_render_params params;
     std::memset(&params, 0, sizeof(params));
     params.width = width;

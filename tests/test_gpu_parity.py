@@ -350,3 +350,10 @@ def test_dropin_program(tmp_path, oracle):
     assert same_bits(img, want)
     assert np.array_equal(u8, oracle.image_to_8bit(img, flip_rows=False, math_mode=1))
     assert img.mean() > 0.01
+    # the same program leaving the tree to the binding (built on the GPU): the same image except where a ray
+    # meets two surfaces at exactly the same distance
+    r = subprocess.run([exe, prefix + "_dev", str(w), str(h), str(s), "devicebvh"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    img_dev = np.fromfile(prefix + "_dev.img", np.float32).reshape(h, w, 3)
+    assert np.mean(bits(img_dev) != bits(want)) <= 2e-3
