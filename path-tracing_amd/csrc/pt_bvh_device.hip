@@ -232,10 +232,17 @@ __global__ void __launch_bounds__(kBlock) hierarchyKernel(const uint64_t* __rest
         parent[0] = 0xFFFFFFFFu;
 }
 
-// boxes of the inner nodes, bottom-up from every leaf; the second arrival at a node does the merge
+// boxes of the inner nodes, bottom-up from every leaf; the second arrival at a node does the merge.
+// The boxes of inner nodes travel between threads of different blocks, possibly on different
+// dies with their own L2: they are written and read with agent-scope atomic accesses (coherent per
+// location, no cache-wide write-back or invalidate as a fence of that scope would cost on every
+// step), and a thread's stores are complete (vmcnt) before it counts itself in.
+PT_DEV void storeCoherent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PT_DEV float loadCoherent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ void __launch_bounds__(kBlock) refitKernel(const float4* __restrict__ leafBox, const uint32_t* __restrict__ order,
                                                       const uint2* __restrict__ children, const uint32_t* __restrict__ parent,
-                                                      int n, float4* __restrict__ innerBox, uint32_t* __restrict__ arrived)
+                                                      int n, float* innerBox /* 8 floats per inner node */, uint32_t* arrived)
 {
     const int p = int(blockIdx.x * kBlock + threadIdx.x);
     if (p >= n)
@@ -243,30 +250,27 @@ __global__ void __launch_bounds__(kBlock) refitKernel(const float4* __restrict__
     uint32_t node = parent[n - 1 + p];
     while (node != 0xFFFFFFFFu) {
         const uint32_t k = node & 0x7FFFFFFFu;
-        __threadfence();
-        if (atomicAdd(&arrived[k], 1u) == 0u)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_fetch_add(&arrived[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
             return; // the other child's thread will come by
-        __threadfence();
         const uint2 ch = children[k];
-        float4 a0, a1, b0, b1;
-        if (ch.x >= uint32_t(n - 1)) {
-            const uint32_t s = order[ch.x - uint32_t(n - 1)];
-            a0 = leafBox[2 * size_t(s)];
-            a1 = leafBox[2 * size_t(s) + 1];
-        } else {
-            a0 = innerBox[2 * size_t(ch.x)];
-            a1 = innerBox[2 * size_t(ch.x) + 1];
+        float a[6], b[6];
+        const uint32_t child[2] = { ch.x, ch.y };
+        for (int c = 0; c < 2; c++) {
+            float* dst = c == 0 ? a : b;
+            if (child[c] >= uint32_t(n - 1)) {
+                const uint32_t s = order[child[c] - uint32_t(n - 1)];
+                const float4 b0 = leafBox[2 * size_t(s)], b1 = leafBox[2 * size_t(s) + 1];
+                dst[0] = b0.x; dst[1] = b0.y; dst[2] = b0.z; dst[3] = b0.w; dst[4] = b1.x; dst[5] = b1.y;
+            } else {
+                for (int i = 0; i < 6; i++)
+                    dst[i] = loadCoherent(&innerBox[8 * size_t(child[c]) + i]);
+            }
         }
-        if (ch.y >= uint32_t(n - 1)) {
-            const uint32_t s = order[ch.y - uint32_t(n - 1)];
-            b0 = leafBox[2 * size_t(s)];
-            b1 = leafBox[2 * size_t(s) + 1];
-        } else {
-            b0 = innerBox[2 * size_t(ch.y)];
-            b1 = innerBox[2 * size_t(ch.y) + 1];
-        }
-        innerBox[2 * size_t(k) + 0] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), fmaxf(a0.w, b0.w));
-        innerBox[2 * size_t(k) + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), 0.0f, 0.0f);
+        for (int i = 0; i < 3; i++)
+            storeCoherent(&innerBox[8 * size_t(k) + i], fminf(a[i], b[i]));
+        for (int i = 3; i < 6; i++)
+            storeCoherent(&innerBox[8 * size_t(k) + i], fmaxf(a[i], b[i]));
         node = parent[k];
     }
 }
@@ -449,8 +453,8 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
     const uint32_t innerBlocks = (uint32_t(n - 1) + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(hierarchyKernel, dim3(innerBlocks), dim3(kBlock), 0, stream, codesSorted, n, children, range, parent);
     HIP_TRY(hipMemsetAsync(arrived, 0, size_t(n) * 4, stream));
-    hipLaunchKernelGGL(refitKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, leafBox, orderSorted, children, parent, n, innerBox,
-                       arrived);
+    hipLaunchKernelGGL(refitKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, leafBox, orderSorted, children, parent, n,
+                       reinterpret_cast<float*>(innerBox), arrived);
     const uint32_t allBlocks = (uint32_t(2 * n - 1) + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(layoutKernel, dim3(allBlocks), dim3(kBlock), 0, stream, leafBox, innerBox, orderSorted, children, range, parent,
                        n, scene->nodes, place);
