@@ -149,3 +149,45 @@ def test_single_surface_scene(oracle):
         d = s.desc()
         assert np.array_equal(dev.render_samples(cam, q).view(np.uint32),
                               oracle.render_samples(C.byref(d), cam, q, math_mode=1).view(np.uint32))
+
+
+def test_degenerate_inputs(oracle):
+    """Surfaces with identical boxes (equal Morton codes are told apart by position), a scene flat in one
+    axis, and two surfaces only."""
+    cam = scenes.build("spheres")[1]
+    q = pt.make_params(20, 14, 2, seed=4)
+    for variant in ("duplicates", "flat", "two"):
+        s = pt.FlatScene()
+        light = s.material_light((6.0, 6.0, 6.0))
+        grey = s.material_lambertian(s.texture_constant((0.6, 0.6, 0.6)))
+        if variant == "duplicates":
+            for _ in range(37):
+                s.add_sphere((0.5, 0.0, 0.0), 0.8, grey)
+            for _ in range(5):
+                s.add_sphere((-1.5, 1.0, 0.5), 0.4, light, is_light=True)
+            s.add_sphere((0.0, -50.0, 0.0), 49.0, grey)
+        elif variant == "flat":
+            for i in range(9):
+                for j in range(9):
+                    s.add_sphere((i - 4.0, 0.0, j - 4.0), 0.0, grey)  # radius 0: boxes are points in one plane
+            s.add_sphere((0.0, 0.0, 0.0), 0.0, light, is_light=True)
+        else:
+            s.add_sphere((0.0, 0.0, 0.0), 1.0, grey)
+            s.add_sphere((0.0, 4.0, 0.0), 1.0, light, is_light=True)
+        s.build_bvh()
+        with pt.DeviceScene(s) as dev:
+            dev.build_bvh_device()
+            nodes = dev.get_bvh()
+            check_tree(nodes, len(s.surfaces))
+            s.nodes = nodes
+            d = s.desc()
+            for env in (None, "1"):
+                if env:
+                    os.environ["PT_NO_LDS_SCENE"] = env
+                try:
+                    got = dev.render_samples(cam, q)
+                finally:
+                    if env:
+                        del os.environ["PT_NO_LDS_SCENE"]
+                assert np.array_equal(got.view(np.uint32),
+                                      oracle.render_samples(C.byref(d), cam, q, math_mode=1).view(np.uint32)), (variant, env)
