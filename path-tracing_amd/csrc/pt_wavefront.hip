@@ -1152,7 +1152,6 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     HIP_TRY(hipMemsetAsync(pools[1].d_s, 0, size_t(nSlots) * 16, stream));
     HIP_TRY(hipMemsetAsync(pools[0].cls, kClsEmpty, size_t(nSlots), stream));
     const uint64_t maxIters = (uint64_t(b.totalIds) / nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
-    const int checkEvery = 16;
     const bool dyn = sc->hasDynamic;
     const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
         && std::getenv("PT_NO_LDS_SCENE") == nullptr;
@@ -1165,6 +1164,9 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     bool exhaustedBefore = false; // every path number had been handed out at the previous check already
     uint64_t iter = 0;
     for (;;) {
+        // the counters are read back every 16 iterations while paths are being started, every other
+        // iteration once the last one has been (the pool then drains within a few iterations)
+        const int checkEvery = exhaustedBefore ? 2 : 16;
         for (int k = 0; k < checkEvery; k++, iter++) {
             const int parity = int(iter & 1);
             const Pool& cur = pools[iter & 1];
