@@ -343,6 +343,25 @@ int pt_image_to_8bit(int device, const float* rgb, int width, int height, float 
 int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_stream);
 int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity, uint64_t* out_count);
 
+/* The two image passes of the reference's importer (rank 3 of what comes after
+ * the render loop), on the GPU.
+ * pt_texture_from_bytes: what TextureImage's constructor gets from stb_image
+ * for an 8-bit RGB file (reference src/15/texture_image.hpp:17-33): texel =
+ * (float) pow(sample / 255.0f, linearize ? 2.2f : 1.0f), rows bottom-up if
+ * flip_rows (the reference flips on load).  rgb8 = width * height * 3 bytes in
+ * file order, out = width * height * 3 floats (the texels of a PT_TEX_IMAGE).
+ * pt_bump_to_normal_map: bumpMapToNormalMap (reference src/15/import.hpp:47-67)
+ * on the texels of a bump map (first component = height).
+ * The _device variants take device pointers on `device` and a HIP stream. */
+int pt_texture_from_bytes(int device, const unsigned char* rgb8, int width, int height, int linearize, int flip_rows,
+                          float* out_texels);
+int pt_texture_from_bytes_device(int device, const unsigned char* d_rgb8, int width, int height, int linearize,
+                                 int flip_rows, float* d_out_texels, void* hip_stream);
+int pt_bump_to_normal_map(int device, const float* bump_texels, int width, int height, float bump_factor,
+                          float* out_texels);
+int pt_bump_to_normal_map_device(int device, const float* d_bump_texels, int width, int height, float bump_factor,
+                                 float* d_out_texels, void* hip_stream);
+
 /* ------------------------------------------------------- host-side helpers -- */
 
 /* Build the acceleration structure over [t0, t1] exactly as

@@ -799,6 +799,42 @@ int ref_image_to_8bit(const float* rgb, int width, int height, float urq_max, fl
     return 0;
 }
 
+// TextureImage's constructor (reference src/15/texture_image.hpp:17-33) on an 8-bit RGB image given as
+// bytes in file order: the bytes are wrapped into a binary PPM in memory and go through the same stb_image
+// calls (gamma, vertical flip, stbi_loadf).  out: width * height * 3 floats.
+int ref_texture_from_bytes(const unsigned char* rgb8, int width, int height, int linearize, float* out)
+{
+    std::string ppm = "P6\n" + std::to_string(width) + " " + std::to_string(height) + "\n255\n";
+    std::vector<unsigned char> file(ppm.begin(), ppm.end());
+    file.insert(file.end(), rgb8, rgb8 + size_t(width) * height * 3);
+    stbi_ldr_to_hdr_gamma(linearize ? 2.2f : 1.0f);
+    stbi_set_flip_vertically_on_load(1);
+    int w, h, n;
+    float* data = stbi_loadf_from_memory(file.data(), int(file.size()), &w, &h, &n, 3);
+    if (!data || w != width || h != height)
+        return fail("stb_image did not read the image");
+    std::memcpy(out, data, size_t(w) * h * 3 * sizeof(float));
+    stbi_image_free(data);
+    return 0;
+}
+
+// bumpMapToNormalMap (reference src/15/import.hpp:47-67) on the texels of a bump map
+int ref_bump_to_normal_map(const float* texels, int width, int height, float bump_factor, float* out)
+{
+    std::vector<vec3> img(size_t(width) * height);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = vec3(texels[3 * i + 0], texels[3 * i + 1], texels[3 * i + 2]);
+    TextureImage bump(img, width, height);
+    std::unique_ptr<Texture> normalMap(bumpMapToNormalMap(&bump, bump_factor, width, height));
+    const TextureImage* result = static_cast<const TextureImage*>(normalMap.get());
+    for (size_t i = 0; i < img.size(); i++) {
+        out[3 * i + 0] = result->img[i].x();
+        out[3 * i + 1] = result->img[i].y();
+        out[3 * i + 2] = result->img[i].z();
+    }
+    return 0;
+}
+
 // Animation::at(t) of a POD animation -> POD transform (slerp included)
 int ref_kat_animation(const pt_animation* a, float t, pt_transform* out)
 {

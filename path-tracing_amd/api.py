@@ -55,6 +55,12 @@ def lib():
         L.pt_scene_desc_free.restype = None
         L.pt_scene_create.argtypes = [C.POINTER(abi.pt_scene_desc), C.c_int, C.POINTER(C.c_void_p)]
         L.pt_scene_update_bvh.argtypes = [C.c_void_p, C.POINTER(abi.pt_bvh_node), C.c_uint64]
+        L.pt_texture_from_bytes.argtypes = [C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(C.c_float)]
+        L.pt_texture_from_bytes_device.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_void_p]
+        L.pt_bump_to_normal_map.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
+        L.pt_bump_to_normal_map_device.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.pt_scene_build_bvh_device.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.pt_scene_get_bvh.argtypes = [C.c_void_p, C.POINTER(abi.pt_bvh_node), C.c_uint64, C.POINTER(C.c_uint64)]
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp]
@@ -164,6 +170,26 @@ def image_to_8bit_device(d_rgb_ptr, width, height, d_out_ptr, device=0, urq=None
     mx, br = urq if urq else (0.0, 1.0)
     _check(lib().pt_image_to_8bit_device(device, C.c_void_p(d_rgb_ptr), width, height, mx, br, 1 if flip_rows else 0,
                                          C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def texture_from_bytes(rgb8, device=0, linearize=True, flip_rows=True):
+    """What TextureImage's constructor makes of an 8-bit RGB file (reference src/15/texture_image.hpp:17-33), on the
+    GPU: (H, W, 3) uint8 in file order -> (H, W, 3) float32 texels, bottom row first if flip_rows."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    h, w = rgb8.shape[0], rgb8.shape[1]
+    out = np.empty((h, w, 3), np.float32)
+    _check(lib().pt_texture_from_bytes(device, rgb8.ctypes.data_as(C.POINTER(C.c_ubyte)), w, h, int(linearize),
+                                       int(flip_rows), _f(out)))
+    return out
+
+
+def bump_to_normal_map(texels, bump_factor, device=0):
+    """bumpMapToNormalMap (reference src/15/import.hpp:47-67) on the GPU: (H, W, 3) float32 -> (H, W, 3) float32."""
+    texels = np.ascontiguousarray(texels, np.float32)
+    h, w = texels.shape[0], texels.shape[1]
+    out = np.empty((h, w, 3), np.float32)
+    _check(lib().pt_bump_to_normal_map(device, _f(texels), w, h, float(bump_factor), _f(out)))
+    return out
 
 
 def n_samples(p):

@@ -127,6 +127,16 @@ def gen_mesh_vectors(R):
     rs.close()
 
 
+def gen_ingest(R):
+    """The importer's image passes: TextureImage's constructor through stb_image (gamma 2.2 and 1), and
+    bumpMapToNormalMap at two bump factors (reference src/15/texture_image.hpp:17-33, import.hpp:47-67)."""
+    img = scenes.ingest_image()
+    lin = R.texture_from_bytes(img, linearize=True)
+    raw = R.texture_from_bytes(img, linearize=False)
+    np.savez(out("ingest.npz"), linear=lin, raw=raw, normal_1=R.bump_to_normal_map(raw, 1.0),
+             normal_8=R.bump_to_normal_map(raw, 8.0))
+
+
 def gen_output_stage(R):
     img = scenes.output_stage_image()
     np.savez(out("output_stage.npz"), plain=R.image_to_8bit(img), urq=R.image_to_8bit(img, urq=(2.5, 20.0)),
@@ -169,7 +179,7 @@ def main():
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     R = refbind.Reference()
-    steps = {"cornell": gen_cornell, "cornell_vectors": gen_cornell_vectors, "families": gen_family_vectors,
+    steps = {"ingest": gen_ingest, "cornell": gen_cornell, "cornell_vectors": gen_cornell_vectors, "families": gen_family_vectors,
              "mesh": gen_mesh_vectors, "output": gen_output_stage, "kat": gen_kat}
     for name, fn in steps.items():
         if args.only and args.only != name:

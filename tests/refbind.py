@@ -67,6 +67,21 @@ class Reference:
         """The reference's to8Bit (after uniformRationalQuantization if urq) in saveImageAsPPM's row order."""
         return _to_8bit(self.lib.ref_image_to_8bit, self._check, img, urq, flip_rows)
 
+    def texture_from_bytes(self, rgb8, linearize=True):
+        """TextureImage's constructor (stb_image, gamma, vertical flip) on an (h, w, 3) uint8 image in file order."""
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        h, w = rgb8.shape[:2]
+        out = np.empty((h, w, 3), np.float32)
+        self._check(self.lib.ref_texture_from_bytes(rgb8.ctypes.data_as(C.POINTER(C.c_ubyte)), w, h, int(linearize), _f(out)))
+        return out
+
+    def bump_to_normal_map(self, texels, bump_factor):
+        texels = np.ascontiguousarray(texels, np.float32)
+        h, w = texels.shape[:2]
+        out = np.empty((h, w, 3), np.float32)
+        self._check(self.lib.ref_bump_to_normal_map(_f(texels), w, h, C.c_float(bump_factor), _f(out)))
+        return out
+
     def lookat(self, eye, center, up=(0.0, 1.0, 0.0)):
         T = abi.pt_transform()
         e = np.asarray(eye, np.float32)
@@ -310,6 +325,21 @@ class Oracle:
 
     def image_to_8bit(self, img, urq=None, flip_rows=True, math_mode=1):
         return _to_8bit(self.lib.oracle_image_to_8bit, self._check, img, urq, flip_rows, math_mode)
+
+    def texture_from_bytes(self, rgb8, linearize=True, flip_rows=True):
+        rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+        h, w = rgb8.shape[:2]
+        out = np.empty((h, w, 3), np.float32)
+        self._check(self.lib.oracle_texture_from_bytes(rgb8.ctypes.data_as(C.POINTER(C.c_ubyte)), w, h, int(linearize),
+                                                       int(flip_rows), _f(out)))
+        return out
+
+    def bump_to_normal_map(self, texels, bump_factor):
+        texels = np.ascontiguousarray(texels, np.float32)
+        h, w = texels.shape[:2]
+        out = np.empty((h, w, 3), np.float32)
+        self._check(self.lib.oracle_bump_to_normal_map(_f(texels), w, h, C.c_float(bump_factor), _f(out)))
+        return out
 
     def kat_warp(self, which, u0, u1, param=None, math_mode=0):
         u0 = np.ascontiguousarray(u0, np.float32)

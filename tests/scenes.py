@@ -314,3 +314,18 @@ def output_stage_image():
     img[1, :8] = np.linspace(0.0, 0.0062616, 24, dtype=np.float32).reshape(8, 3)
     img[2, :8] = 1.0
     return img
+
+
+def ingest_image():
+    """Seeded 8-bit RGB test image in file order (all 256 sample values occur) with a smooth height field in
+    its first channel, for the importer's two image passes."""
+    rng = np.random.default_rng(7)
+    h, w = 37, 53
+    y, x = np.mgrid[0:h, 0:w]
+    height = 127.5 + 90.0 * np.sin(x * 0.37) * np.cos(y * 0.29) + rng.normal(0.0, 12.0, (h, w))
+    img = rng.integers(0, 256, (h, w, 3))
+    img[..., 0] = np.clip(height, 0, 255)
+    img[0, :, 1] = np.arange(w) * 255 // (w - 1)
+    flat = img.reshape(-1)
+    flat[:256] = np.arange(256)  # every sample value at least once
+    return flat.reshape(h, w, 3).astype(np.uint8)

@@ -357,3 +357,21 @@ def test_dropin_program(tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     img_dev = np.fromfile(prefix + "_dev.img", np.float32).reshape(h, w, 3)
     assert np.mean(bits(img_dev) != bits(want)) <= 2e-3
+
+
+def test_importer_image_passes(golden_dir, oracle):
+    """pt_texture_from_bytes and pt_bump_to_normal_map against the oracle and the reference-generated vectors,
+    bit for bit; also on an image large enough for many blocks."""
+    img = scenes.ingest_image()
+    g = np.load(os.path.join(golden_dir, "ingest.npz"))
+    for key, lin in (("linear", True), ("raw", False)):
+        got = pt.texture_from_bytes(img, linearize=lin)
+        assert np.array_equal(bits(got), bits(g[key]))
+    assert np.array_equal(bits(pt.texture_from_bytes(img, flip_rows=False)), bits(g["linear"][::-1]))
+    for key, f in (("normal_1", 1.0), ("normal_8", 8.0)):
+        assert np.array_equal(bits(pt.bump_to_normal_map(g["raw"], f)), bits(g[key]))
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (700, 900, 3)).astype(np.uint8)
+    tex = pt.texture_from_bytes(big, linearize=False)
+    assert np.array_equal(bits(tex), bits(oracle.texture_from_bytes(big, linearize=False)))
+    assert np.array_equal(bits(pt.bump_to_normal_map(tex, 3.0)), bits(oracle.bump_to_normal_map(tex, 3.0)))

@@ -10,5 +10,5 @@ FLAGS="-std=c++17 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -I../../include
 /opt/rocm/bin/hipcc $FLAGS --offload-arch=gfx950 -c pt_wavefront.hip -o /tmp/ptv_$name/pt_wavefront.o &
 /opt/rocm/bin/hipcc $FLAGS --offload-arch=gfx950 -c pt_kernels.hip -o /tmp/ptv_$name/pt_kernels.o &
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 pt_host.o pt_bvh_device.o /tmp/ptv_$name/pt_kernels.o /tmp/ptv_$name/pt_wavefront.o -o ../lib/variants/libptamd_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 pt_host.o pt_bvh_device.o pt_ingest.o /tmp/ptv_$name/pt_kernels.o /tmp/ptv_$name/pt_wavefront.o -o ../lib/variants/libptamd_$name.so
 echo built $name
