@@ -296,6 +296,9 @@ def main():
         # vector flops are priced over the whole launch sequence (they are spread over all kernels)
         ach_tf = flops_ps * launch_samples / (last_ms * 1e-3) / 1e12
         traffic, traffic_note = measured_traffic(args.workload, dominant)
+        if args.bvh == "device":
+            traffic, traffic_note = None, "the committed PMC passes were taken with the reference's tree"
+
         result = {
             "metric": "path samples/sec at 1080p", "value": value, "unit": "path samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
