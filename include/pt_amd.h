@@ -343,8 +343,7 @@ int pt_image_to_8bit(int device, const float* rgb, int width, int height, float 
 int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_stream);
 int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity, uint64_t* out_count);
 
-/* The two image passes of the reference's importer (rank 3 of what comes after
- * the render loop), on the GPU.
+/* The two per-texel image passes of the reference's importer, on the GPU.
  * pt_texture_from_bytes: what TextureImage's constructor gets from stb_image
  * for an 8-bit RGB file (reference src/15/texture_image.hpp:17-33): texel =
  * (float) pow(sample / 255.0f, linearize ? 2.2f : 1.0f), rows bottom-up if
