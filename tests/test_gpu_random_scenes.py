@@ -96,3 +96,55 @@ def test_random_scene(seed, oracle):
         finally:
             del os.environ["PT_NO_LDS_SCENE"]
         assert np.array_equal(dev.render_samples(cam, p).view(np.uint32), want2), "device-built tree, in LDS"
+
+
+def soup_scene(seed, n_tri, n_sph):
+    """A soup of overlapping random triangles and spheres: deep trees with heavily overlapping boxes, so the
+    nearer-child-first walk meets many near-ties and stack overflows and leans on its second pass."""
+    rng = np.random.default_rng(seed)
+    s = pt.FlatScene()
+    grey = s.material_lambertian(s.texture_constant((0.6, 0.6, 0.6)))
+    mirror = s.material_mirror(s.texture_constant((0.9, 0.9, 0.9)))
+    centres = rng.uniform(-5, 5, (n_tri, 1, 3))
+    pos = (centres + rng.normal(0, 0.6, (n_tri, 3, 3))).reshape(-1, 3).astype(np.float32)
+    # some exactly coplanar, edge-sharing pairs: ties in distance
+    pos[3:6] = pos[0:3][[0, 2, 1]] + np.float32(0.0)
+    s.add_mesh(pos, np.arange(3 * n_tri, dtype=np.uint32), grey)
+    for i in range(n_sph):
+        s.add_sphere(tuple(rng.uniform(-5, 5, 3)), float(0.1 + 0.5 * rng.random()), mirror if i % 2 else grey)
+    s.add_sphere((0.0, 9.0, 0.0), 2.0, s.material_light((10.0, 10.0, 10.0)), is_light=True)
+    s.set_envmap_equirect(s.texture_constant((0.3, 0.3, 0.4)))
+    s.build_bvh()
+    cam = pt.make_camera(math.tan(math.radians(30.0)), math.tan(math.radians(30.0)) * 1.5, 8.0, 0.0,
+                         scenes.lookat_animation((0.0, 2.0, 14.0), (0.0, 0.0, 0.0)))
+    return s, cam
+
+
+@pytest.mark.parametrize("seed,n_tri,n_sph", [(1, 600, 40), (2, 4000, 300), (3, 20000, 0)])
+def test_soup(seed, n_tri, n_sph, oracle):
+    s, cam = soup_scene(seed, n_tri, n_sph)
+    d = s.desc()
+    p1 = pt.make_params(160, 100, 1, seed=seed)
+    p = pt.make_params(64, 40, 2, seed=seed)
+    want_hits = oracle.primary_hits(C.byref(d), cam, p1, math_mode=1).tobytes()
+    want = oracle.render_samples(C.byref(d), cam, p, math_mode=1).view(np.uint32)
+    with pt.DeviceScene(s) as dev:
+        for env in (None, "1"):
+            if env:
+                os.environ["PT_NO_LDS_SCENE"] = env
+            try:
+                assert dev.primary_hits(cam, p1).tobytes() == want_hits, env
+                assert np.array_equal(dev.render_samples(cam, p).view(np.uint32), want), env
+            finally:
+                if env:
+                    del os.environ["PT_NO_LDS_SCENE"]
+        os.environ["PT_NO_LDS_SCENE"] = "1"
+        try:
+            dev.build_bvh_device()
+            s.nodes = dev.get_bvh()
+            d2 = s.desc()
+            assert dev.primary_hits(cam, p1).tobytes() == oracle.primary_hits(C.byref(d2), cam, p1, math_mode=1).tobytes()
+            assert np.array_equal(dev.render_samples(cam, p).view(np.uint32),
+                                  oracle.render_samples(C.byref(d2), cam, p, math_mode=1).view(np.uint32))
+        finally:
+            del os.environ["PT_NO_LDS_SCENE"]
