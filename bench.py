@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--bvh", choices=["host", "device"], default="host",
                     help="host: the reference's tree (pt_bvh_build); device: the tree built by pt_scene_build_bvh_device")
     args = ap.parse_args()
+    if os.environ.get("PT_BENCH_WATCHDOG"):
+        # where every thread stands, should a run stop making progress
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PT_BENCH_WATCHDOG"]), exit=False, file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -228,7 +232,11 @@ def main():
             events.append((e0, e1))
         if world > 1 and not frames:
             if rehearsal:
-                dist.all_reduce(out, op=dist.ReduceOp.SUM)  # gloo has no reduce on device tensors
+                # gloo, ranks sharing one GPU: reduce a host copy (gloo's own staging of device tensors was seen
+                # to stall now and then when two processes share a device)
+                host = out.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                out.copy_(host)
             else:
                 dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0 and mode == "batches":
