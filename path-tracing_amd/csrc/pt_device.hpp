@@ -23,6 +23,7 @@ using namespace ptv;
 constexpr uint32_t kInner = 0xFFFFFFFFu; // "no surface": a node step that did not end on a hit leaf
 constexpr uint32_t kInnerBit = 0x80000000u; // DevNode.leaf of an inner node: kInnerBit | index of its second child
 constexpr uint32_t kLeafRowBit = 0x40000000u; // in a link of the `wide` table, see DevScene
+constexpr uint32_t kMeshMask = 0x00FFFFFFu;  // surface row 1, word 3: mesh number | material type << 24
 
 // surface kinds (SurfRec word 3 of row 0)
 enum : uint32_t {
@@ -47,8 +48,8 @@ struct DevMesh {
 // surface id, or kInnerBit | second child for an inner node.  Inner nodes have
 // their first child at index + 1.
 // surf: 3 x float4 per surface; triangles (A.xyz, bits kind), (B.xyz, bits
-// mesh), (C.xyz, bits triangle-in-mesh); spheres (centre.xyz, bits kind),
-// (radius, bits sphere, -, -), unused.  surfAttr and matConst repeat, per
+// mesh | material type << 24), (C.xyz, bits triangle-in-mesh); spheres
+// (centre.xyz, bits kind), (radius, bits sphere, -, bits material type << 24), unused.  surfAttr and matConst repeat, per
 // surface and per material, what shading would otherwise reach through two or
 // three dependent table reads (mesh -> index list -> vertices; material ->
 // texture -> value).
@@ -376,6 +377,7 @@ struct HitLite {
     float a;
     float u, v; // triangle barycentrics
     bool backside;
+    uint32_t matClass; // type of the surface's material (from the surface row), for ordering the shading work
 };
 
 // AABB::hit, reference src/15/aabb.hpp:41-60, also giving the distance at which the box is
@@ -480,7 +482,7 @@ PT_DEV void triVertices(const DevScene& sc, uint32_t sid, float time, V3& A, V3&
     B = v3(r1.x, r1.y, r1.z);
     C = v3(r2.x, r2.y, r2.z);
     if (fbits(r0.w) == kTriDynamic) {
-        const DevMesh& m = sc.meshes[fbits(r1.w)];
+        const DevMesh& m = sc.meshes[fbits(r1.w) & kMeshMask];
         Xform T = animationAt<PM>(sc.animations[m.animation], time);
         A = apply(T, A);
         B = apply(T, B);
@@ -521,7 +523,7 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
         float4 r2 = surf[3 * sid + 2];
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
         if (DYN && kind == kTriDynamic) {
-            const DevMesh& m = sc.meshes[fbits(r1.w)];
+            const DevMesh& m = sc.meshes[fbits(r1.w) & kMeshMask];
             Xform T = animationAt<PM>(sc.animations[m.animation], ray.time);
             A = apply(T, A);
             B = apply(T, B);
@@ -536,6 +538,7 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
         out.u = u;
         out.v = v;
         out.backside = bs;
+        out.matClass = fbits(r1.w) >> 24;
         return true;
     }
     V3 c = v3(r0.x, r0.y, r0.z);
@@ -554,6 +557,7 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
     out.u = 0.0f;
     out.v = 0.0f;
     out.backside = false;
+    out.matClass = fbits(r1.w) >> 24;
     return true;
 }
 
@@ -619,6 +623,7 @@ PT_DEV HitLite noHit()
     h.a = 0.0f;
     h.u = h.v = 0.0f;
     h.backside = false;
+    h.matClass = 0;
     return h;
 }
 
@@ -665,7 +670,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
         Quat rot = Quat{ 0.0f, 0.0f, 0.0f, 1.0f };
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
         if (animated) {
-            const DevMesh& m = sc.meshes[fbits(r1.w)];
+            const DevMesh& m = sc.meshes[fbits(r1.w) & kMeshMask];
             Xform T = animationAt<PM>(sc.animations[m.animation], ray.time);
             rot = T.rotation;
             if (kind == kTriDynamic) {
@@ -759,7 +764,7 @@ __device__ inline V3 surfaceDirection(const DevScene& sc, uint32_t sid, V3 origi
     float first = rng.in01();
     if (kind <= kTriDynamic) {
         float4 r2 = sc.surf[3 * size_t(sid) + 2];
-        const DevMesh& m = sc.meshes[fbits(r1.w)];
+        const DevMesh& m = sc.meshes[fbits(r1.w) & kMeshMask];
         V3 A, B, C;
         if (m.animation >= 0) {
             // sample the unposed triangle, then pose the point

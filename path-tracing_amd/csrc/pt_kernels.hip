@@ -437,6 +437,10 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     }
 
     auto bitsf = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    // the type of a surface's material travels with the surface (shading work is ordered by it)
+    auto matClassOf = [&](int32_t material) {
+        return uint32_t(std::min<int32_t>(std::max<int32_t>(d->materials[material].type, 0), 7));
+    };
     bool hasDynamic = false;
     std::vector<float4> surf(3 * d->n_surfaces);
     std::vector<uint4> surfAttr(d->n_surfaces);
@@ -466,7 +470,9 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
                 }
             }
             surf[3 * i + 0] = make_float4(A.x, A.y, A.z, bitsf(kind));
-            surf[3 * i + 1] = make_float4(B.x, B.y, B.z, bitsf(s.owner));
+            if (uint32_t(s.owner) > kMeshMask)
+                return fail(PT_ERR_LIMIT, "more than 2^24 meshes");
+            surf[3 * i + 1] = make_float4(B.x, B.y, B.z, bitsf(uint32_t(s.owner) | (matClassOf(m.material) << 24)));
             surf[3 * i + 2] = make_float4(C.x, C.y, C.z, bitsf(s.index));
             const uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
                 | (m.animation >= 0 ? 8u : 0u);
@@ -489,7 +495,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
                 }
             }
             surf[3 * i + 0] = make_float4(c.x, c.y, c.z, bitsf(kind));
-            surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, 0.0f);
+            surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, bitsf(matClassOf(q.material) << 24));
             surf[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material));
         }

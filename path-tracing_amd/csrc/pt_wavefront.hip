@@ -43,7 +43,8 @@ using ptint::fail;
 namespace {
 
 enum : uint32_t { kEmpty = 0, kActive = 1 }; // state of a record: no path / a path with a ray to trace
-enum : uint8_t { kClsEmpty = 0, kClsHit = 1, kClsMiss = 2 };
+enum : uint8_t { kClsEmpty = 0, kClsMiss = 1, kClsHit = 2 }; // a hit is kClsHit + the type of the surface's material
+constexpr uint32_t kHitClasses = 8;
 constexpr uint32_t kDestIsSample = 0x80000000u;
 constexpr uint32_t kBackEmits = 0x40000000u;
 constexpr uint32_t kLightMask = 0x3FFFFFFFu;
@@ -56,7 +57,7 @@ struct Pool {
     float4* thr_n; // throughput, bits: number of random draws made
     float4* rad_p; // radiance so far, bits: index of the path in the sample buffer
     uint2* key;    // generator key of the path
-    uint8_t* cls;  // what the tracing found for the record: kClsEmpty / kClsHit / kClsMiss (classifyKernel reads
+    uint8_t* cls;  // what the tracing found for the record: kClsEmpty / kClsMiss / kClsHit + class (classifyKernel reads
                    // only this byte per record)
     float4* sh_o;  // shadow ray queue: origin, time
     float4* sh_d;  //   direction, bits: destination (record of the pool traced next, or sample-buffer index)
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
             if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
-                pool.cls[item] = best.sid == PT_NO_HIT ? kClsMiss : kClsHit;
+                pool.cls[item] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
             } else {
                 shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
             }
@@ -590,6 +591,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                     bool bs;
                     if (triTest(A, B, C, ray, 0.0001f, cull, a, u, v, bs)) {
                         h.sid = link;
+                        h.matClass = fbits(r1.w) >> 24;
                         h.a = a;
                         h.u = u;
                         h.v = v;
@@ -651,7 +653,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
             } else if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
-                pool.cls[item] = best.sid == PT_NO_HIT ? kClsMiss : kClsHit;
+                pool.cls[item] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
             } else if (best.sid != PT_NO_HIT) {
                 const float4 payload = pool.sh_c[itemBase + item];
                 if (best.sid == (fbits(payload.w) & kLightMask)) {
@@ -696,7 +698,7 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
             const HitLite best = closestHit<false, DYN>(sc, ray, 0.0001f, bound, nullptr);
             pool.hit[e] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                      fbits(best.a), fbits(best.u), fbits(best.v));
-            pool.cls[e] = best.sid == PT_NO_HIT ? kClsMiss : kClsHit;
+            pool.cls[e] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
         } else {
             const uint32_t q = e & ~kRetryIsShadow;
             const float4 so = pool.sh_o[q], sd = pool.sh_d[q], payload = pool.sh_c[q];
@@ -745,18 +747,54 @@ constexpr uint32_t kClassifyBlock = 1024;
 __global__ void __launch_bounds__(kClassifyBlock) classifyKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
                                                                  float* __restrict__ samples)
 {
-    __shared__ uint32_t lds[2 * (kClassifyBlock / 64 + 1)];
+    // hits go to the list ordered by the type of their material within the block's 1024 records, so that the
+    // 64 entries a wave of shadeHitsKernel takes mostly run the same material code
+    constexpr uint32_t kWaves = kClassifyBlock / 64;
+    __shared__ uint32_t count[kHitClasses][kWaves]; // hits of class c in wave w; then their first place in the block's run
+    __shared__ uint32_t blockBase;
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
     const uint32_t slot = blockIdx.x * kClassifyBlock + threadIdx.x; // the grid covers the records exactly
     const uint8_t cls = pool.cls[slot];
-    const bool hit = cls == kClsHit;
+    const bool hit = cls >= kClsHit;
+    const uint32_t cl = hit ? min(uint32_t(cls - kClsHit), kHitClasses - 1u) : 0u;
     const uint32_t shard = blockIdx.x % kShards;
-    uint32_t posH, unused;
-    blockReserve2<kClassifyBlock / 64>(&counters[(kCtrHit + shard) * kCtrStride], hit,
-                                       &counters[(kCtrHit + shard) * kCtrStride], false, lds, posH, unused);
+    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t rank = 0; // among the wave's hits of the same class
+#pragma unroll
+    for (uint32_t c = 0; c < kHitClasses; c++) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(hit && cl == c);
+        if (cl == c)
+            rank = uint32_t(__popcll(m & below));
+        if (lane == 0)
+            count[c][wave] = uint32_t(__popcll(m));
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // class-major running sum over the kHitClasses * kWaves = 128 counts by one wave (two per lane), then one
+        // reservation for the block
+        static_assert(kHitClasses * kWaves == 128, "two counts per lane");
+        uint32_t* flat = &count[0][0];
+        const uint32_t v0 = flat[lane], v1 = flat[64 + lane];
+        uint32_t s0 = v0, s1 = v1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(s0, off, 64), b = __shfl_up(s1, off, 64);
+            if (int(lane) >= off) {
+                s0 += a;
+                s1 += b;
+            }
+        }
+        const uint32_t total0 = __shfl(s0, 63, 64), total = total0 + __shfl(s1, 63, 64);
+        flat[lane] = s0 - v0;
+        flat[64 + lane] = total0 + s1 - v1;
+        if (lane == 0)
+            blockBase = total ? atomicAdd(&counters[(kCtrHit + shard) * kCtrStride], total) : 0u;
+    }
+    __syncthreads();
     if (hit)
-        pool.hitList[size_t(shard) * pool.listCap + posH] = slot;
+        pool.hitList[size_t(shard) * pool.listCap + blockBase + count[cl][wave] + rank] = slot;
     if (cls == kClsMiss) {
         // the ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
         const float4 rad_p = pool.rad_p[slot];
