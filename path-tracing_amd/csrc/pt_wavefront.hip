@@ -69,7 +69,7 @@ struct Pool {
     uint32_t retryCap; // entries per sub-list
     uint32_t* hitList;  // per shard: records whose ray hit a surface (to be shaded)
     uint32_t listCap;   // entries per shard of either list (= the records of the shard's blocks, rounded up)
-    uint32_t nSlots;    // records per pool: a multiple of 1024 * kShards; shard q's region is [q, q + 1) * nSlots / kShards
+    uint32_t nSlots;    // records per pool: a multiple of kClassifyRecords * kShards; shard q's region is [q, q + 1) * nSlots / kShards
 };
 
 // geometry of one batch of paths
@@ -742,33 +742,51 @@ constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK; // threads per block of shadeHi
 // records that need no shading are not loaded by the shading kernel, and all state stores are
 // dense.  New paths lie together in path-number order (neighbouring pixels), which also keeps the
 // camera rays of a wave and their first hits coherent.
-// (1024 threads per block: the atomic per block is what bounds this kernel)
+// A block of 1024 threads takes kClassifyChunks runs of 1024 records, so the hits of 8192 records are ordered
+// together and one reservation serves them all.  What gains is the shading kernel (fewer waves with mixed
+// materials: Cornell 647 -> 610 us per launch); this kernel's own time hardly depends on the number of runs
+// (about half of it is the work for the misses).  8 runs measured best overall, 2/4/16/32 slower.
 constexpr uint32_t kClassifyBlock = 1024;
+#ifndef PT_CLASSIFY_CHUNKS
+#define PT_CLASSIFY_CHUNKS 8
+#endif
+constexpr uint32_t kClassifyChunks = PT_CLASSIFY_CHUNKS;
+constexpr uint32_t kClassifyRecords = kClassifyBlock * kClassifyChunks; // records per block
 __global__ void __launch_bounds__(kClassifyBlock) classifyKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
                                                                  float* __restrict__ samples)
 {
-    // hits go to the list ordered by the type of their material within the block's 1024 records, so that the
+    // hits go to the list ordered by the type of their material within the block's records, so that the
     // 64 entries a wave of shadeHitsKernel takes mostly run the same material code
     constexpr uint32_t kWaves = kClassifyBlock / 64;
     __shared__ uint32_t count[kHitClasses][kWaves]; // hits of class c in wave w; then their first place in the block's run
     __shared__ uint32_t blockBase;
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
-    const uint32_t slot = blockIdx.x * kClassifyBlock + threadIdx.x; // the grid covers the records exactly
-    const uint8_t cls = pool.cls[slot];
-    const bool hit = cls >= kClsHit;
-    const uint32_t cl = hit ? min(uint32_t(cls - kClsHit), kHitClasses - 1u) : 0u;
+    const uint32_t slot0 = blockIdx.x * kClassifyRecords + threadIdx.x; // the grid covers the records exactly
+    uint8_t cls[kClassifyChunks];
+#pragma unroll
+    for (uint32_t j = 0; j < kClassifyChunks; j++)
+        cls[j] = pool.cls[slot0 + j * kClassifyBlock];
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t wave = threadIdx.x >> 6, lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
-    uint32_t rank = 0; // among the wave's hits of the same class
+    uint32_t rank[kClassifyChunks]; // among the wave's hits of the same class: run by run, lane by lane
+#pragma unroll
+    for (uint32_t j = 0; j < kClassifyChunks; j++)
+        rank[j] = 0;
 #pragma unroll
     for (uint32_t c = 0; c < kHitClasses; c++) {
-        const uint64_t m = __builtin_amdgcn_ballot_w64(hit && cl == c);
-        if (cl == c)
-            rank = uint32_t(__popcll(m & below));
+        uint32_t sofar = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kClassifyChunks; j++) {
+            const bool mine = cls[j] >= kClsHit && min(uint32_t(cls[j] - kClsHit), kHitClasses - 1u) == c;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+            if (mine)
+                rank[j] = sofar + uint32_t(__popcll(m & below));
+            sofar += uint32_t(__popcll(m));
+        }
         if (lane == 0)
-            count[c][wave] = uint32_t(__popcll(m));
+            count[c][wave] = sofar;
     }
     __syncthreads();
     if (wave == 0) {
@@ -793,20 +811,26 @@ __global__ void __launch_bounds__(kClassifyBlock) classifyKernel(DevScene sc, Po
             blockBase = total ? atomicAdd(&counters[(kCtrHit + shard) * kCtrStride], total) : 0u;
     }
     __syncthreads();
-    if (hit)
-        pool.hitList[size_t(shard) * pool.listCap + blockBase + count[cl][wave] + rank] = slot;
-    if (cls == kClsMiss) {
-        // the ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
-        const float4 rad_p = pool.rad_p[slot];
-        V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
-        if (sc.envmap.type != PT_ENV_NONE) {
-            const float4 thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
-            radiance = radiance + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
+#pragma unroll
+    for (uint32_t j = 0; j < kClassifyChunks; j++) {
+        const uint32_t slot = slot0 + j * kClassifyBlock;
+        if (cls[j] >= kClsHit) {
+            const uint32_t cl = min(uint32_t(cls[j] - kClsHit), kHitClasses - 1u);
+            pool.hitList[size_t(shard) * pool.listCap + blockBase + count[cl][wave] + rank[j]] = slot;
         }
-        float* p = samples + 3 * size_t(fbits(rad_p.w));
-        p[0] = radiance.x;
-        p[1] = radiance.y;
-        p[2] = radiance.z;
+        if (cls[j] == kClsMiss) {
+            // the ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
+            const float4 rad_p = pool.rad_p[slot];
+            V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
+            if (sc.envmap.type != PT_ENV_NONE) {
+                const float4 thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
+                radiance = radiance + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
+            }
+            float* p = samples + 3 * size_t(fbits(rad_p.w));
+            p[0] = radiance.x;
+            p[1] = radiance.y;
+            p[2] = radiance.z;
+        }
     }
 }
 
@@ -1211,7 +1235,7 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             const Pool& next = pools[(iter + 1) & 1];
             launchTraceFor(sc, cur, stream, parity, dyn, lds);
             sc->kt.begin(KernelTimes::kClassify, stream);
-            hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyBlock), dim3(kClassifyBlock), 0, stream, sc->dev, cur,
+            hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyRecords), dim3(kClassifyBlock), 0, stream, sc->dev, cur,
                                w.counters, w.samples);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
@@ -1269,7 +1293,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
     uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
-    const uint64_t slotUnit = uint64_t(kClassifyBlock) * kShards; // every shard's region and list is whole blocks
+    const uint64_t slotUnit = uint64_t(kClassifyRecords) * kShards; // every shard's region and list is whole blocks
     nSlots = std::max<uint64_t>((nSlots + slotUnit - 1) / slotUnit * slotUnit, slotUnit);
     int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
     if (rc != PT_OK)
