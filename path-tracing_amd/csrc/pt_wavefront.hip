@@ -752,7 +752,7 @@ constexpr uint32_t kClassifyBlock = 1024;
 #endif
 constexpr uint32_t kClassifyChunks = PT_CLASSIFY_CHUNKS;
 constexpr uint32_t kClassifyRecords = kClassifyBlock * kClassifyChunks; // records per block
-__global__ void __launch_bounds__(kClassifyBlock) classifyKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
+__global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
                                                                  float* __restrict__ samples)
 {
     // hits go to the list ordered by the type of their material within the block's records, so that the
@@ -811,15 +811,22 @@ __global__ void __launch_bounds__(kClassifyBlock) classifyKernel(DevScene sc, Po
             blockBase = total ? atomicAdd(&counters[(kCtrHit + shard) * kCtrStride], total) : 0u;
     }
     __syncthreads();
+    uint64_t misses = 0; // bit 8 * j: run j's record is a miss
 #pragma unroll
     for (uint32_t j = 0; j < kClassifyChunks; j++) {
-        const uint32_t slot = slot0 + j * kClassifyBlock;
         if (cls[j] >= kClsHit) {
             const uint32_t cl = min(uint32_t(cls[j] - kClsHit), kHitClasses - 1u);
-            pool.hitList[size_t(shard) * pool.listCap + blockBase + count[cl][wave] + rank[j]] = slot;
+            pool.hitList[size_t(shard) * pool.listCap + blockBase + count[cl][wave] + rank[j]] = slot0 + j * kClassifyBlock;
         }
-        if (cls[j] == kClsMiss) {
+        misses |= uint64_t(cls[j] == kClsMiss) << (8 * j);
+    }
+    static_assert(kClassifyChunks <= 8, "one byte per run in `misses`");
+    // (not unrolled: the environment lookup is a lot of code, and its registers would halve the occupancy)
+#pragma unroll 1
+    for (uint32_t j = 0; j < kClassifyChunks; j++) {
+        if ((misses >> (8 * j)) & 1u) {
             // the ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
+            const uint32_t slot = slot0 + j * kClassifyBlock;
             const float4 rad_p = pool.rad_p[slot];
             V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
             if (sc.envmap.type != PT_ENV_NONE) {
