@@ -1084,6 +1084,45 @@ __device__ inline float lightsPdf(const DevScene& sc, V3 origin, V3 dir, float t
     return sum;
 }
 
+// The same for two directions from one point at once (the scattered direction and the direction to the
+// sampled light, reference src/15/pathtracer.cpp:78-81 and 88-91): every light is read once, and what depends
+// on the light alone (edges, normal, area) is computed once.  Each direction sees the arithmetic of surfaceP.
+__device__ inline void lightsPdf2(const DevScene& sc, V3 origin, V3 dirA, V3 dirB, float time, float& pA, float& pB)
+{
+    const Ray ra = makeRay(origin, dirA, time), rb = makeRay(origin, dirB, time);
+    float sumA = 0.0f, sumB = 0.0f;
+    for (uint32_t i = 0; i < sc.n_lights; i++) {
+        const uint32_t sid = sc.lights[i];
+        const float4 r0 = sc.surf[3 * size_t(sid) + 0];
+        if (fbits(r0.w) <= kTriDynamic) {
+            V3 A, B, C;
+            triVertices(sc, sid, time, A, B, C);
+            float aA, aB, u, v;
+            bool bs;
+            const bool hitA = triTest(A, B, C, ra, 0.0f, kFltMax, aA, u, v, bs);
+            const bool hitB = triTest(A, B, C, rb, 0.0f, kFltMax, aB, u, v, bs);
+            float valA = 0.0f, valB = 0.0f;
+            if (hitA || hitB) {
+                const V3 edgeCross = cross(B - A, C - A);
+                const float edgeCrossLength = ::sqrtf(dot(edgeCross, edgeCross));
+                const V3 faceNormal = edgeCross / edgeCrossLength;
+                const float faceArea = 0.5f * edgeCrossLength;
+                if (hitA)
+                    valA = (aA * aA) / (fabs_(dot(faceNormal, -ra.direction)) * faceArea);
+                if (hitB)
+                    valB = (aB * aB) / (fabs_(dot(faceNormal, -rb.direction)) * faceArea);
+            }
+            sumA += valA;
+            sumB += valB;
+        } else {
+            sumA += surfaceP<false>(sc, sid, ra, nullptr);
+            sumB += surfaceP<false>(sc, sid, rb, nullptr);
+        }
+    }
+    pA = sumA / sc.n_lights;
+    pB = sumB / sc.n_lights;
+}
+
 // pathSample, reference src/15/pathtracer.cpp:50-130
 template <bool COUNT>
 __device__ inline V3 pathSample(const DevScene& sc, const PathParams& pp, Ray ray, Rng<COUNT>& rng, Counters* cnt)

@@ -896,14 +896,15 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
         } else {
             V3 nextThroughput = throughput * sr.attenuation / sr.p;
             if (sr.type == ScatterRandom && sc.n_lights > 0) {
-                float lightsP = lightsPdf<false>(sc, hr.position, sr.direction, ray.time, nullptr);
-                nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
                 uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
                 if (lightIndex >= sc.n_lights)
                     lightIndex = sc.n_lights - 1;
                 const uint32_t lightSurf = sc.lights[lightIndex];
                 V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
-                float lightDirP = lightsPdf<false>(sc, hr.position, lightDir, ray.time, nullptr);
+                // (the two sums over the lights draw no random numbers, so they can be taken together)
+                float lightsP, lightDirP;
+                lightsPdf2(sc, hr.position, sr.direction, lightDir, ray.time, lightsP, lightDirP);
+                nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
                 if (lightDirP > 0.0f) {
                     Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
                     if (lightSR.p > 0.0f) {
