@@ -927,9 +927,17 @@ PT_DEV V3 materialTexture(const DevScene& sc, int mid, const pt_material& m, int
     return textureValue(sc, m.tex[k], tc);
 }
 
+// What Material::scatter read from the material's textures at the hit, kept for scatterToDirection at the same
+// hit (textures are functions of the texture coordinate alone, so the values are the same ones).
+struct MaterialValues {
+    V3 kd, ks, n;
+    float shininess;
+};
+
 // Material::scatter
 template <bool COUNT>
-__device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray& ray, const Hit& hrIn, Rng<COUNT>& rng)
+__device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray& ray, const Hit& hrIn, Rng<COUNT>& rng,
+                                          MaterialValues* keep = nullptr)
 {
     bool backside = hrIn.backside;
     mid = resolveTwoSided(sc, mid, backside);
@@ -948,7 +956,10 @@ __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray
         if (cosTheta <= 0.0f)
             return scatterNone();
         float p = cosTheta / kPi;
-        V3 att = (materialTexture(sc, mid, m, 0, hr.texcoord) / kPi) * cosTheta;
+        V3 albedo = materialTexture(sc, mid, m, 0, hr.texcoord);
+        if (keep)
+            keep->kd = albedo;
+        V3 att = (albedo / kPi) * cosTheta;
         return scatterRandom(dir, p, att);
     }
     case PT_MAT_PHONG: { // material_phong.hpp:48-102
@@ -964,6 +975,12 @@ __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray
         V3 ks = materialTexture(sc, mid, m, 1, hr.texcoord);
         float shininess = materialTexture(sc, mid, m, 2, hr.texcoord).x;
         V3 n = phongNormal(sc, m, hr);
+        if (keep) {
+            keep->kd = kd;
+            keep->ks = ks;
+            keep->n = n;
+            keep->shininess = shininess;
+        }
         V3 v = -ray.direction;
         V3 r = reflect(ray.direction, n);
         float sumKd = kd.x + kd.y + kd.z;
@@ -1032,7 +1049,10 @@ __device__ inline Scatter materialScatter(const DevScene& sc, int mid, const Ray
 
 // Material::scatterToDirection.  MaterialTwoSided does not override it in the
 // reference, so a two-sided material answers like the base class: no scatter.
-__device__ inline Scatter materialScatterToDirection(const DevScene& sc, int mid, const Ray& ray, const Hit& hr, V3 dir)
+// `kept`: the values materialScatter read at this hit for this very material (the caller passes them only after
+// a random scatter of material `mid` itself, not of a side of a two-sided one), or null.
+__device__ inline Scatter materialScatterToDirection(const DevScene& sc, int mid, const Ray& ray, const Hit& hr, V3 dir,
+                                                     const MaterialValues* kept = nullptr)
 {
     const pt_material& m = sc.materials[mid];
     if (m.type == PT_MAT_LAMBERTIAN) { // material_lambertian.hpp:40-49
@@ -1040,18 +1060,19 @@ __device__ inline Scatter materialScatterToDirection(const DevScene& sc, int mid
         if (cosTheta <= 0.0f)
             return scatterNone();
         float p = cosTheta / kPi;
-        V3 att = (materialTexture(sc, mid, m, 0, hr.texcoord) / kPi) * cosTheta;
+        V3 albedo = kept ? kept->kd : materialTexture(sc, mid, m, 0, hr.texcoord);
+        V3 att = (albedo / kPi) * cosTheta;
         return scatterRandom(dir, p, att);
     }
     if (m.type == PT_MAT_PHONG) { // material_phong.hpp:104-117
-        V3 n = phongNormal(sc, m, hr);
+        V3 n = kept ? kept->n : phongNormal(sc, m, hr);
         float cosTheta = dot(n, dir);
         if (cosTheta <= 0.0f)
             return scatterNone();
         float p = cosTheta / kPi;
-        V3 kd = materialTexture(sc, mid, m, 0, hr.texcoord);
-        V3 ks = materialTexture(sc, mid, m, 1, hr.texcoord);
-        float shininess = materialTexture(sc, mid, m, 2, hr.texcoord).x;
+        V3 kd = kept ? kept->kd : materialTexture(sc, mid, m, 0, hr.texcoord);
+        V3 ks = kept ? kept->ks : materialTexture(sc, mid, m, 1, hr.texcoord);
+        float shininess = kept ? kept->shininess : materialTexture(sc, mid, m, 2, hr.texcoord).x;
         V3 att = phongBrdf(n, dir, -ray.direction, kd, ks, shininess) * cosTheta;
         return scatterRandom(dir, p, att);
     }

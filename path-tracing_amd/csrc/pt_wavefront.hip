@@ -889,7 +889,8 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
         hl.u = __uint_as_float(hw.z);
         hl.v = __uint_as_float(hw.w);
         Hit hr = makeHit(sc, ray, hl);
-        Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng);
+        MaterialValues mv;
+        Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng, &mv);
         radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
         if (sr.type == ScatterNone) {
             finished = true;
@@ -906,7 +907,9 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
                 lightsPdf2(sc, hr.position, sr.direction, lightDir, ray.time, lightsP, lightDirP);
                 nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
                 if (lightDirP > 0.0f) {
-                    Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir);
+                    // (a two-sided material scattered as one of its sides and answers scatterToDirection itself)
+                    Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir,
+                                                                 sc.materials[hr.material].type == PT_MAT_TWOSIDED ? nullptr : &mv);
                     if (lightSR.p > 0.0f) {
                         float weight = powerHeuristicMIS(lightDirP, lightSR.p);
                         // everything of the contribution but the light's emission, which the
