@@ -66,7 +66,8 @@ struct DevScene {
     const float4* surf;
     const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24);
                              // spheres (sphere index, 0, 0, material | flags << 24).  flags: 1 normals,
-                             // 2 texcoords, 4 tangents, 8 mesh has a pose
+                             // 2 texcoords, 4 tangents, 8 mesh has a pose, 16 the material reads texture
+                             // coordinates, 32 the material reads the tangent
     const float4* matConst;  // per material 2 rows: (value of tex[0] if constant, bits mask), (value of tex[1]
                              // if constant, x of tex[2] if constant); mask bit k = tex[k] is a constant texture
     const float* positions;
@@ -665,7 +666,7 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     uint32_t kind = fbits(r0.w);
     if (kind <= kTriDynamic) {
         float4 r2 = sc.surf[3 * size_t(h.sid) + 2];
-        const uint32_t flags = (attr.w >> 24) & 0xFu;
+        const uint32_t flags = attr.w >> 24;
         const bool animated = (flags & 8u) != 0;
         Quat rot = Quat{ 0.0f, 0.0f, 0.0f, 1.0f };
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
@@ -694,7 +695,8 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
         if (h.backside)
             nrm = -nrm;
         V2 tc;
-        if (flags & 2u) {
+        // (texture coordinates and tangent only for a material that reads them)
+        if ((flags & 2u) && (flags & 16u)) {
             const float* a = sc.texcoords + 2 * i0;
             const float* b = sc.texcoords + 2 * i1;
             const float* c = sc.texcoords + 2 * i2;
@@ -702,18 +704,18 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
         } else {
             tc = V2{ 0.0f, 0.0f };
         }
-        V3 tng;
-        if (flags & 4u) {
-            tng = w * v3(sc.tangents + 3 * i0) + u * v3(sc.tangents + 3 * i1) + v * v3(sc.tangents + 3 * i2);
-            if (animated)
-                tng = rotate(rot, tng);
-            tng = tng - dot(nrm, tng) * nrm;
-            if (dot(tng, tng) > kEps)
-                tng = normalize(tng);
-        } else {
-            tng = v3(0.0f);
+        V3 tng = v3(0.0f);
+        if (flags & 32u) {
+            if (flags & 4u) {
+                tng = w * v3(sc.tangents + 3 * i0) + u * v3(sc.tangents + 3 * i1) + v * v3(sc.tangents + 3 * i2);
+                if (animated)
+                    tng = rotate(rot, tng);
+                tng = tng - dot(nrm, tng) * nrm;
+                if (dot(tng, tng) > kEps)
+                    tng = normalize(tng);
+            }
+            tng = normalize(tng);
         }
-        tng = normalize(tng);
         hr.normal = nrm;
         hr.texcoord = tc;
         hr.tangent = tng;
@@ -727,14 +729,23 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     uint32_t sphereId;
     sphereCR(sc, h.sid, ray.time, c, r, T, sphereId);
     V3 n = normalize(hr.position - c);
-    V3 rn = rotate(T.rotation, n);
-    float alpha = ptm::atan2f(rn.x, rn.z);
-    float beta = ptm::asinf(min_(1.0f, max_(-1.0f, rn.y)));
-    float u = (alpha + kPi) / (2.0f * kPi);
-    float v = (beta + 0.5f * kPi) / kPi;
-    float sa, ca;
-    ptm::sincosf(alpha, sa, ca);
-    V3 t = v3(ca, 0.0f, -sa);
+    const uint32_t flags = attr.w >> 24;
+    float u = 0.0f, v = 0.0f;
+    V3 t = v3(0.0f);
+    if (flags & 48u) {
+        V3 rn = rotate(T.rotation, n);
+        float alpha = ptm::atan2f(rn.x, rn.z);
+        if (flags & 16u) {
+            float beta = ptm::asinf(min_(1.0f, max_(-1.0f, rn.y)));
+            u = (alpha + kPi) / (2.0f * kPi);
+            v = (beta + 0.5f * kPi) / kPi;
+        }
+        if (flags & 32u) {
+            float sa, ca;
+            ptm::sincosf(alpha, sa, ca);
+            t = v3(ca, 0.0f, -sa);
+        }
+    }
     bool backside = false;
     if (dot(n, -ray.direction) < 0.0f) {
         backside = true;

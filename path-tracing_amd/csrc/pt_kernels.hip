@@ -17,6 +17,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "pt_amd.h"
@@ -441,6 +442,23 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     auto matClassOf = [&](int32_t material) {
         return uint32_t(std::min<int32_t>(std::max<int32_t>(d->materials[material].type, 0), 7));
     };
+    // what the material of a surface will ask of a hit record: texture coordinates (16) if it looks up a texture
+    // that is not constant, the tangent (32) if it has a normal map; a two-sided material asks what its sides ask
+    std::function<uint32_t(int32_t, int)> materialNeeds = [&](int32_t material, int depth) -> uint32_t {
+        const pt_material& m = d->materials[material];
+        auto varies = [&](int k) { return m.tex[k] >= 0 && d->textures[m.tex[k]].type != PT_TEX_CONSTANT; };
+        switch (m.type) {
+        case PT_MAT_LAMBERTIAN:
+        case PT_MAT_MIRROR:
+            return varies(0) ? 16u : 0u;
+        case PT_MAT_PHONG:
+            return ((varies(0) || varies(1) || varies(2) || m.tex[3] >= 0 || m.tex[4] >= 0) ? 16u : 0u) | (m.tex[4] >= 0 ? 32u : 0u);
+        case PT_MAT_TWOSIDED:
+            return depth < 10 ? (materialNeeds(m.front, depth + 1) | materialNeeds(m.back, depth + 1)) : 48u;
+        default:
+            return 0u;
+        }
+    };
     bool hasDynamic = false;
     std::vector<float4> surf(3 * d->n_surfaces);
     std::vector<uint4> surfAttr(d->n_surfaces);
@@ -475,7 +493,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
             surf[3 * i + 1] = make_float4(B.x, B.y, B.z, bitsf(uint32_t(s.owner) | (matClassOf(m.material) << 24)));
             surf[3 * i + 2] = make_float4(C.x, C.y, C.z, bitsf(s.index));
             const uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
-                | (m.animation >= 0 ? 8u : 0u);
+                | (m.animation >= 0 ? 8u : 0u) | materialNeeds(m.material, 0);
             surfAttr[i] = make_uint4(m.first_vertex + idx[0], m.first_vertex + idx[1], m.first_vertex + idx[2],
                                      uint32_t(m.material) | (flags << 24));
         } else {
@@ -497,7 +515,7 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
             surf[3 * i + 0] = make_float4(c.x, c.y, c.z, bitsf(kind));
             surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, bitsf(matClassOf(q.material) << 24));
             surf[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material));
+            surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material) | (materialNeeds(q.material, 0) << 24));
         }
     }
 
