@@ -133,6 +133,47 @@ def test_family_samples(name, golden_dir, oracle):
     assert rel_outliers(got, golden) <= limit
 
 
+def test_materials_that_read_texture_coordinates_and_tangents(oracle):
+    """Texture coordinates and tangent of a hit are computed only for surfaces whose material reads them (decided
+    per surface at upload).  Every way a material can read them, on spheres and on a mesh: a normal map on a
+    sphere, a two-sided material with a textured side, a mirror and a shininess taken from images, an opacity map;
+    beside materials that read neither.  Samples bit-equal to the oracle's, scene in LDS and in memory."""
+    rng = np.random.default_rng(21)
+    s = pt.FlatScene()
+    grey = s.material_lambertian(s.texture_constant((0.6, 0.6, 0.6)))
+    light = s.material_light((9.0, 9.0, 8.0))
+    scenes.room(s, grey, light)
+    image = lambda w, h: s.texture_image(scenes.image_texture(rng, w, h))
+    normal_map = s.texture_image((rng.random((8, 8, 3), dtype=np.float32) * 0.4 + np.array([0.3, 0.3, 0.6], np.float32)))
+    const = s.texture_constant
+    bumpy = s.material_phong(const((0.5, 0.3, 0.2)), const((0.4, 0.4, 0.4)), const(30.0), -1, normal_map)
+    s.add_sphere((-2.0, -3.0, 0.0), 1.0, bumpy)
+    s.add_sphere((0.0, -3.0, -1.5), 1.0, s.material_twosided(grey, s.material_lambertian(image(8, 4))))
+    s.add_sphere((2.0, -3.0, 0.0), 1.0, s.material_mirror(image(6, 6)))
+    s.add_sphere((0.0, -3.3, 1.5), 0.7, s.material_twosided(bumpy, s.material_base()))
+    shin = s.texture_image(np.full((4, 4, 3), 20.0, np.float32) + rng.random((4, 4, 3), dtype=np.float32) * 40)
+    opacity = s.texture_image(np.repeat(rng.random((5, 5, 1), dtype=np.float32) * 0.7 + 0.3, 3, axis=2))
+    pos, nrm, tc, idx = scenes.uv_sphere_mesh(0.9, (-0.3, -1.0, 0.3))
+    s.add_mesh(pos, idx, s.material_phong(const((0.2, 0.4, 0.6)), const((0.3, 0.3, 0.3)), shin, opacity, -1), nrm, tc)
+    pos, nrm, tc, idx = scenes.uv_sphere_mesh(0.6, (2.2, -0.8, -1.0))
+    s.add_mesh(pos, idx, s.material_phong(const((0.5, 0.5, 0.1)), const((0.2, 0.2, 0.2)), const(15.0)), nrm, tc)
+    s.build_bvh()
+    cam = scenes.build("materials")[1]
+    p = pt.make_params(32, 24, 3, seed=13)
+    d = s.desc()
+    want = oracle.render_samples(C.byref(d), cam, p, math_mode=1)
+    for env in (None, "1"):
+        if env:
+            os.environ["PT_NO_LDS_SCENE"] = env
+        try:
+            with pt.DeviceScene(s) as dev:
+                got = dev.render_samples(cam, p)
+        finally:
+            if env:
+                del os.environ["PT_NO_LDS_SCENE"]
+        assert same_bits(got, want), env
+
+
 def test_converged_image_rmse(cornell, golden_dir):
     scene, cam, dev = cornell
     ref = np.load(os.path.join(golden_dir, "cornell_converged_96_mt4096.npy"))  # reference generator, 4096 spp
