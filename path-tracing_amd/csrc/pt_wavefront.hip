@@ -993,7 +993,11 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
 }
 
 // `next` = the pool being filled: the places of every region behind the paths that go on
-__global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, Batch b, uint32_t* __restrict__ counters)
+#ifndef PT_GENERATE_ROOT_TEST
+#define PT_GENERATE_ROOT_TEST 1
+#endif
+__global__ void __launch_bounds__(256) generateKernel(DevScene sc, Pool next, RenderArgs a, Batch b, uint32_t* __restrict__ counters,
+                                                      float* __restrict__ samples)
 {
     const uint32_t regionCap = next.nSlots / kShards; // a multiple of 256
     const uint32_t first = blockIdx.x * 256u;
@@ -1025,6 +1029,31 @@ __global__ void __launch_bounds__(256) generateKernel(Pool next, RenderArgs a, B
     rng.n = 0;
     rng.cnt = nullptr;
     Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+#if PT_GENERATE_ROOT_TEST
+    // A camera ray that misses the box of the whole tree ends here as the tracing and classifying kernels would
+    // end it (the walk's first step is this very test, reference src/15/bvh.hpp:183-213, and a miss adds the
+    // environment to radiance 0 with throughput 1, src/15/pathtracer.cpp:60-62): its place stays empty in this
+    // iteration instead of carrying a path through two more kernels.
+    {
+        bool rootHit = false;
+        if (sc.n_nodes > 0) {
+            const float4 n0 = sc.nodes[0], n1 = sc.nodes[1];
+            rootHit = aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, kFltMax);
+        }
+        if (!rootHit) {
+            V3 radiance = v3(0.0f);
+            if (sc.envmap.type != PT_ENV_NONE)
+                radiance = radiance + v3(1.0f) * envmapValue(sc, ray.direction);
+            float* out = samples + 3 * size_t(sLocal * b.npix + uint32_t(ly * a.tw + lx));
+            out[0] = radiance.x;
+            out[1] = radiance.y;
+            out[2] = radiance.z;
+            next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
+            next.cls[place] = kClsEmpty;
+            return;
+        }
+    }
+#endif
     next.o_t[place] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
     next.d_s[place] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
     next.thr_n[place] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
@@ -1254,7 +1283,7 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
                                sc->dev, cur, next, a.pp, w.counters, parity, w.samples, shadowCap);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kGenerate, stream);
-            hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, next, a, b, w.counters);
+            hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, sc->dev, next, a, b, w.counters, w.samples);
             sc->kt.end(stream);
         }
         HIP_TRY(hipGetLastError());
