@@ -245,9 +245,20 @@ const char* pt_version(void);
 int pt_device_count(void);
 
 /* Upload a flat scene to GPU `device`.  Replaces the implicit "scene is in
- * host memory" state at reference src/15/pathtracer.cpp:198.  The desc must
- * include the BVH (n_bvh_nodes == 2 * n_surfaces - 1).  The host arrays may
- * be freed after the call. */
+ * host memory" state at reference src/15/pathtracer.cpp:198.  The desc
+ * includes the BVH (n_bvh_nodes == 2 * n_surfaces - 1), or none at all
+ * (n_bvh_nodes == 0): then pt_scene_build_bvh_device or pt_scene_update_bvh
+ * has to give the scene a tree before the first render; until then every
+ * pt_render* / pt_trace_rays / pt_primary_hits call fails with
+ * PT_ERR_INVALID_ARGUMENT.  The host arrays may be freed after the call.
+ *
+ * Calls on one scene: the work areas, the tree and the timing state of a
+ * scene serve one call at a time.  The library serialises them itself: an
+ * entry point holds the scene's lock while it enqueues its work, and its
+ * stream first waits (hipStreamWaitEvent) for the work the previous call on
+ * that scene enqueued, whichever stream that was.  So two threads, or two
+ * streams, may use one scene; they do not overlap on the GPU.  Use one scene
+ * handle per stream for concurrent rendering. */
 int pt_scene_create(const pt_scene_desc* desc, int device, pt_scene** out_scene);
 
 /* Replace the acceleration structure (per-frame rebuild over a new shutter
@@ -264,7 +275,14 @@ int pt_render(pt_scene* scene, const pt_camera* camera, const pt_render_params* 
               float* out_rgb);
 
 /* Same, into device memory on the scene's GPU, enqueued on `hip_stream`
- * (a hipStream_t passed as void*; NULL = default stream).  Asynchronous. */
+ * (a hipStream_t passed as void*; NULL = default stream).  The call returns
+ * before the image is complete -- the last tracing and the summing kernel may
+ * still be running; the image is complete for work enqueued on `hip_stream`
+ * after the call, or after synchronising that stream -- but it is not a
+ * non-blocking call: while paths are in flight the host reads the path
+ * counters back every few iterations (hipStreamSynchronize on `hip_stream`)
+ * to learn when the batch has drained, so it cannot be captured into a graph.
+ * max_path_segments is at most 65535 (PT_ERR_LIMIT beyond). */
 int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                      float* d_out_rgb, void* hip_stream);
 

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -113,9 +114,20 @@ inline bool get(FILE* f, std::vector<T>& v)
     uint64_t count = 0;
     if (std::fread(&count, sizeof(count), 1, f) != 1)
         return false;
-    if (count > (uint64_t(1) << 36) / sizeof(T)) // 64 GiB sanity bound
+    // the elements must be in the file: a truncated or hostile count is refused before any memory is taken
+    const long here = std::ftell(f);
+    if (here < 0 || std::fseek(f, 0, SEEK_END) != 0)
         return false;
-    v.resize(count);
+    const long end = std::ftell(f);
+    if (end < here || std::fseek(f, here, SEEK_SET) != 0)
+        return false;
+    if (count > uint64_t(end - here) / sizeof(T))
+        return false;
+    try {
+        v.resize(count);
+    } catch (const std::exception&) {
+        return false;
+    }
     return count == 0 || std::fread(v.data(), sizeof(T), count, f) == count;
 }
 

@@ -237,6 +237,13 @@ __global__ void __launch_bounds__(kBlock) hierarchyKernel(const uint64_t* __rest
 // dies with their own L2: they are written and read with agent-scope atomic accesses (coherent per
 // location, no cache-wide write-back or invalidate as a fence of that scope would cost on every
 // step), and a thread's stores are complete (vmcnt) before it counts itself in.
+// What this leans on is the memory system of gfx950 rather than the language's memory model (under which a
+// relaxed counter orders nothing): agent-scope atomic loads and stores are carried out at the level all compute
+// units share, past the per-unit caches; a wave's stores have been acknowledged by that level once its vmcnt is 0;
+// and the counter's atomic is carried out at that same level afterwards.  The thread that sees the count at 1
+// therefore reads, from that level, what the first arrival stored before counting itself in.  The "memory" clobber
+// keeps the compiler from moving the accesses across the wait.  The release/acquire form of the counter is correct
+// by the model too, and 25 times slower here (a write-back and an invalidate of a whole L2 per step).
 PT_DEV void storeCoherent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PT_DEV float loadCoherent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -400,7 +407,12 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         return fail(PT_ERR_LIMIT, "too many surfaces for the device builder");
     const int n = int(n64);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, stream);
+    HIP_TRY(call.status);
+    // until every step below has succeeded the scene has no tree: a call that fails half way leaves a scene that
+    // refuses to render rather than one with a partly rewritten tree
+    scene->dev.n_nodes = 0;
+    scene->dev.wide = nullptr;
     const DevScene& sc = scene->dev;
     const uint32_t leafBlocks = (uint32_t(n) + kBlock - 1) / kBlock;
 
@@ -444,6 +456,7 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         HIP_TRY(hipStreamSynchronize(stream));
         scene->dev.n_nodes = 1;
         scene->dev.wide = scene->wide; // no inner node: no row is ever read
+        HIP_TRY(call.done(stream));
         return PT_OK;
     }
     hipLaunchKernelGGL(reduceBoundsKernel, dim3(1), dim3(kBlock), 0, stream, blockBounds, leafBlocks, bounds);
@@ -485,28 +498,28 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         scene->dev.qbase[a] = rlo[a];
         scene->dev.qstep[a] = st;
     }
-    scene->dev.n_nodes = uint32_t(2 * n - 1);
     if (gridOk) {
         hipLaunchKernelGGL(wideRowsKernel, dim3(innerBlocks), dim3(kBlock), 0, stream, sc, scene->nodes, children, range, place,
                            orderSorted, n, v3(scene->dev.qbase[0], scene->dev.qbase[1], scene->dev.qbase[2]),
                            v3(scene->dev.qstep[0], scene->dev.qstep[1], scene->dev.qstep[2]), scene->wide);
         HIP_TRY(hipGetLastError());
-        scene->dev.wide = scene->wide;
-    } else {
-        scene->dev.wide = nullptr; // storage-order walk only
     }
+    HIP_TRY(call.done(stream));
+    scene->dev.wide = gridOk ? scene->wide : nullptr; // without rows: storage-order walk only
+    scene->dev.n_nodes = uint32_t(2 * n - 1);
     return PT_OK;
 }
 
 int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity, uint64_t* out_count)
-{
+try {
     if (!scene || !out_count)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     const uint64_t n = scene->dev.n_nodes;
     *out_count = n;
     if (!out_nodes || capacity < n)
         return out_nodes ? fail(PT_ERR_INVALID_ARGUMENT, "node buffer too small") : PT_OK;
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<float4> rows(2 * n);
     if (n > 0)
@@ -524,6 +537,8 @@ int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity,
         o.link = (leaf & kInnerBit) ? (uint64_t(leaf & ~kInnerBit) * 2 + 1) : uint64_t(leaf) * 2;
     }
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 } // extern "C"

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -225,6 +226,19 @@ int fail(int code, const std::string& msg)
     return code;
 }
 
+int caught()
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return fail(PT_ERR_LIMIT, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(PT_ERR_INVALID_ARGUMENT, std::string("unexpected failure: ") + e.what());
+    } catch (...) {
+        return fail(PT_ERR_INVALID_ARGUMENT, "unexpected failure");
+    }
+}
+
 } // namespace ptint
 
 using ptint::fail;
@@ -242,7 +256,7 @@ const char* pt_version(void)
 }
 
 int pt_scene_desc_validate(const pt_scene_desc* d)
-{
+try {
     if (!d)
         return fail(PT_ERR_INVALID_ARGUMENT, "null scene description");
     if (d->abi_version != PT_ABI_VERSION)
@@ -394,10 +408,12 @@ int pt_scene_desc_validate(const pt_scene_desc* d)
         }
     }
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_bvh_build(const pt_scene_desc* d, float t0, float t1, pt_bvh_node* out_nodes, uint32_t* out_depth)
-{
+try {
     if (!d || !out_nodes)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     if (d->n_surfaces == 0)
@@ -418,12 +434,14 @@ int pt_bvh_build(const pt_scene_desc* d, float t0, float t1, pt_bvh_node* out_no
     if (b.maxDepth > 128)
         return fail(PT_ERR_LIMIT, "acceleration structure deeper than 128 levels");
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_mesh_compute_tangents(const float* positions, const float* normals, const float* texcoords,
                              uint32_t n_vertices, const uint32_t* indices, uint32_t n_triangles,
                              float* out_tangents)
-{
+try {
     // mesh.hpp:10-55
     if (!positions || !normals || !texcoords || !indices || !out_tangents)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
@@ -461,10 +479,12 @@ int pt_mesh_compute_tangents(const float* positions, const float* normals, const
         out_tangents[3 * i + 2] = t.z;
     }
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_scene_desc_load(const char* path, pt_scene_desc** out_desc)
-{
+try {
     if (!path || !out_desc)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     OwnedDesc* od = new OwnedDesc;
@@ -480,10 +500,12 @@ int pt_scene_desc_load(const char* path, pt_scene_desc** out_desc)
     }
     *out_desc = &od->desc;
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_scene_desc_save(const pt_scene_desc* desc, const char* path)
-{
+try {
     if (!desc || !path)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     int rc = pt_scene_desc_validate(desc);
@@ -492,6 +514,8 @@ int pt_scene_desc_save(const pt_scene_desc* desc, const char* path)
     if (!ptio::save(*desc, path))
         return fail(PT_ERR_IO, std::string("cannot write scene file ") + path);
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 void pt_scene_desc_free(pt_scene_desc* desc)

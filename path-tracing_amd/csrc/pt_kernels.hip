@@ -322,6 +322,11 @@ int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_
         return fail(PT_ERR_INVALID_ARGUMENT, "tile rectangle outside the image");
     if (s0 < 0 || s1 > p->sqrt_spp * p->sqrt_spp || s0 > s1)
         return fail(PT_ERR_INVALID_ARGUMENT, "sample range outside [0, sqrt_spp^2]");
+    if (scene->dev.n_nodes == 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "scene has no acceleration structure yet (pt_scene_build_bvh_device or pt_scene_update_bvh)");
+    // (the path records keep the segment number in 16 bits)
+    if (p->max_path_segments > 65535)
+        return fail(PT_ERR_LIMIT, "max_path_segments above 65535");
     if (camera->has_animation
         && (camera->animation.type < PT_ANIM_IDENTITY || camera->animation.type > PT_ANIM_TWOKEY))
         return fail(PT_ERR_UNSUPPORTED, "camera animation has an unknown type");
@@ -387,6 +392,8 @@ void pt_scene_destroy(pt_scene* scene)
     if (!scene)
         return;
     DeviceGuard g(scene->device);
+    if (scene->pending)
+        (void)hipEventSynchronize(scene->evDone);
     ptWavefrontRelease(scene);
     for (void* p : scene->owned)
         (void)hipFree(p);
@@ -396,11 +403,13 @@ void pt_scene_destroy(pt_scene* scene)
         (void)hipEventDestroy(scene->evStart);
     if (scene->evStop)
         (void)hipEventDestroy(scene->evStop);
+    if (scene->evDone)
+        (void)hipEventDestroy(scene->evDone);
     delete scene;
 }
 
 int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
-{
+try {
     if (!d || !out_scene)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     *out_scene = nullptr;
@@ -604,16 +613,19 @@ int pt_scene_create(const pt_scene_desc* d, int device, pt_scene** out_scene)
     dev.n_surfaces = uint32_t(d->n_surfaces);
     dev.n_lights = uint32_t(d->n_lights);
     dev.envmap = d->envmap;
-    if (hipEventCreate(&sc->evStart) != hipSuccess || hipEventCreate(&sc->evStop) != hipSuccess) {
+    if (hipEventCreate(&sc->evStart) != hipSuccess || hipEventCreate(&sc->evStop) != hipSuccess
+        || hipEventCreateWithFlags(&sc->evDone, hipEventDisableTiming) != hipSuccess) {
         pt_scene_destroy(sc);
         return fail(PT_ERR_DEVICE, "cannot create timing events");
     }
     *out_scene = sc;
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_nodes)
-{
+try {
     if (!scene || !nodes)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
     if (n_nodes != 2 * scene->n_surfaces - 1)
@@ -627,9 +639,11 @@ int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_no
     int rc = buildDeviceNodes(nodes, n_nodes, dn);
     if (rc != PT_OK)
         return rc;
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(scene->nodes, dn.data(), dn.size() * sizeof(float4), hipMemcpyHostToDevice));
+    scene->dev.n_nodes = uint32_t(n_nodes);
     std::vector<uint4> wide;
     if (buildWideNodes(nodes, n_nodes, scene->hostSurf, wide, scene->dev.qbase, scene->dev.qstep)) {
         if (!wide.empty())
@@ -639,6 +653,8 @@ int pt_scene_update_bvh(pt_scene* scene, const pt_bvh_node* nodes, uint64_t n_no
         scene->dev.wide = nullptr;
     }
     return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* d_out_rgb,
@@ -648,8 +664,12 @@ int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_p
     int rc = checkRender(scene, camera, params, d_out_rgb, a);
     if (rc != PT_OK)
         return rc;
-    DeviceGuard g(scene->device);
-    return launchRender(scene, a, d_out_rgb, static_cast<hipStream_t>(hip_stream), nullptr);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    SceneCall call(scene, stream);
+    HIP_TRY(call.status);
+    rc = launchRender(scene, a, d_out_rgb, stream, nullptr);
+    HIP_TRY(call.done(stream));
+    return rc;
 }
 
 static int renderToHost(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* out_rgb,
@@ -659,7 +679,8 @@ static int renderToHost(pt_scene* scene, const pt_camera* camera, const pt_rende
     int rc = checkRender(scene, camera, params, out_rgb, a);
     if (rc != PT_OK)
         return rc;
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     const size_t bytes = size_t(3) * a.p.width * a.p.height * sizeof(float);
     float* d_out = nullptr;
     unsigned long long* d_cnt = nullptr;
@@ -730,7 +751,8 @@ int pt_scene_profile(pt_scene* scene, int enable)
 {
     if (!scene)
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_profile: null scene");
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     HIP_TRY(hipDeviceSynchronize());
     scene->kt.collect();
     if (enable)
@@ -743,7 +765,8 @@ int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, in
 {
     if (!scene || !count || (capacity > 0 && !out))
         return fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_kernel_times: null argument");
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     HIP_TRY(hipDeviceSynchronize());
     scene->kt.collect();
     static const char* const names[KernelTimes::kKinds] = { "generateKernel", "traceKernel", "shadeHitsKernel",
@@ -871,7 +894,8 @@ int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_
         return PT_OK;
     if (n > (uint64_t(1) << 31))
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     if (!useMegakernel())
         return ptWavefrontSamples(scene, a, out_rgb_per_sample);
     float* d_out = nullptr;
@@ -899,7 +923,8 @@ int pt_primary_hits(pt_scene* scene, const pt_camera* camera, const pt_render_pa
         return PT_OK;
     if (n > (uint64_t(1) << 31))
         return fail(PT_ERR_LIMIT, "too many samples for one call");
-    DeviceGuard g(scene->device);
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     pt_hit* d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(pt_hit)));
     hipLaunchKernelGGL(primaryHitsKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, a, n, d_out);
@@ -923,7 +948,10 @@ int pt_trace_rays(pt_scene* scene, uint64_t n, const float* origins, const float
         return PT_OK;
     if (n > (uint64_t(1) << 31))
         return fail(PT_ERR_LIMIT, "too many rays for one call");
-    DeviceGuard g(scene->device);
+    if (scene->dev.n_nodes == 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "scene has no acceleration structure yet");
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     pt_hit* d_out = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 3 * sizeof(float));
@@ -933,17 +961,29 @@ int pt_trace_rays(pt_scene* scene, uint64_t n, const float* origins, const float
     if (e == hipSuccess) e = hipMemcpy(d_o, origins, n * 3 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, directions, n * 3 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && times) e = hipMemcpy(d_t, times, n * sizeof(float), hipMemcpyHostToDevice);
+    int rc = PT_OK;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(traceRaysKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, n, d_o,
-                           d_d, d_t, amin, amax, d_out);
-        e = hipGetLastError();
+        // with the bounds of the render loop (reference src/15/pathtracer.cpp:60) the rays go through the tracing
+        // kernels a render of this scene uses; other bounds, or PT_TRACE_RAYS=simple, take the one-lane-per-ray walk
+        const char* how = std::getenv("PT_TRACE_RAYS");
+        if (amin == 0.0001f && amax == kFltMax && !(how && std::strcmp(how, "simple") == 0)) {
+            rc = ptWavefrontTraceRays(scene, n, d_o, d_d, d_t, d_out, nullptr);
+        } else {
+            hipLaunchKernelGGL(traceRaysKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, n, d_o,
+                               d_d, d_t, amin, amax, d_out);
+            e = hipGetLastError();
+        }
     }
+    if (rc != PT_OK)
+        e = hipErrorUnknown;
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out_hits, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost);
     if (d_o) (void)hipFree(d_o);
     if (d_d) (void)hipFree(d_d);
     if (d_t) (void)hipFree(d_t);
     if (d_out) (void)hipFree(d_out);
+    if (rc != PT_OK)
+        return rc;
     if (e != hipSuccess)
         return fail(PT_ERR_DEVICE, std::string("trace_rays: ") + hipGetErrorString(e));
     return PT_OK;

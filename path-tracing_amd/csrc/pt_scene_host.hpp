@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -151,10 +152,41 @@ struct pt_scene {
     bool hasDynamic = false; // some surface or sphere has a time-dependent (two-key) pose
     WavefrontBuffers wf;
     KernelTimes kt;
+    // The work areas above, the tree and the timing state belong to one call at a time: every entry point that
+    // touches them holds `mu` while it enqueues, and makes its stream wait for `evDone`, which the previous such
+    // call recorded behind its last kernel (calls may come from different threads and on different streams).
+    std::mutex mu;
+    hipEvent_t evDone = nullptr;
+    bool pending = false;
+};
+
+// One call on a scene: takes the scene's lock, selects its GPU, and orders `stream` behind the previous call's work.
+struct SceneCall {
+    std::lock_guard<std::mutex> lock;
+    DeviceGuard guard;
+    pt_scene* scene;
+    hipError_t status = hipSuccess;
+    SceneCall(pt_scene* sc, hipStream_t stream) : lock(sc->mu), guard(sc->device), scene(sc)
+    {
+        if (!guard.ok)
+            status = hipErrorInvalidDevice;
+        else if (sc->pending)
+            status = hipStreamWaitEvent(stream, sc->evDone, 0);
+    }
+    // everything this call enqueued on `stream` is what the next call has to wait for
+    hipError_t done(hipStream_t stream)
+    {
+        hipError_t e = hipEventRecord(scene->evDone, stream);
+        if (e == hipSuccess)
+            scene->pending = true;
+        return e;
+    }
 };
 
 
 // pt_wavefront.hip
 int ptWavefrontRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);
 int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out_pixel_major);
+int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, const float* d_dirs, const float* d_times,
+                         pt_hit* d_out, hipStream_t stream);
 void ptWavefrontRelease(pt_scene* scene);

@@ -1091,6 +1091,53 @@ __global__ void __launch_bounds__(256) resolveKernel(const float* __restrict__ s
     }
 }
 
+// Caller-supplied rays through the tracing kernels of the renderer: every ray becomes the ray of a path
+// record, one tracing step runs, and the hit words of the records are turned into pt_hit.
+__global__ void __launch_bounds__(256) fillRaysKernel(Pool pool, uint64_t n, const float* __restrict__ origins,
+                                                      const float* __restrict__ dirs, const float* __restrict__ times)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x; // the grid covers the records exactly
+    if (slot < n) {
+        pool.o_t[slot] = make_float4(origins[3 * size_t(slot) + 0], origins[3 * size_t(slot) + 1], origins[3 * size_t(slot) + 2],
+                                     times ? times[slot] : 0.0f);
+        pool.d_s[slot] = make_float4(dirs[3 * size_t(slot) + 0], dirs[3 * size_t(slot) + 1], dirs[3 * size_t(slot) + 2],
+                                     __uint_as_float(kActive << 16));
+    } else {
+        pool.d_s[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
+    }
+    pool.cls[slot] = kClsEmpty;
+}
+
+__global__ void __launch_bounds__(256) collectHitsKernel(DevScene sc, Pool pool, uint64_t n, pt_hit* __restrict__ out)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n)
+        return;
+    pt_hit r;
+    r.surface = PT_NO_HIT;
+    r.material = PT_NO_HIT;
+    r.a = 0.0f;
+    r.backside = 0;
+    if (pool.cls[slot] >= kClsHit) {
+        const uint4 hw = pool.hit[slot];
+        const float4 o_t = pool.o_t[slot], d_s = pool.d_s[slot];
+        const Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+        HitLite hl;
+        hl.sid = hw.x & 0x7FFFFFFFu;
+        hl.backside = (hw.x >> 31) != 0;
+        hl.a = __uint_as_float(hw.y);
+        hl.u = __uint_as_float(hw.z);
+        hl.v = __uint_as_float(hw.w);
+        hl.matClass = 0;
+        const Hit hr = makeHit(sc, ray, hl);
+        r.surface = hl.sid;
+        r.material = uint32_t(hr.material);
+        r.a = hl.a;
+        r.backside = hr.backside ? 1u : 0u;
+    }
+    out[slot] = r;
+}
+
 uint64_t envU64(const char* name, uint64_t dflt)
 {
     const char* v = std::getenv(name);
@@ -1200,6 +1247,12 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
 // node + surface tables up to this size are traced from LDS
 constexpr size_t kLdsGeoLimit = 16 * 1024;
 
+bool sceneFitsLds(const pt_scene* sc)
+{
+    return (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
+        && std::getenv("PT_NO_LDS_SCENE") == nullptr;
+}
+
 // the tracing step of one iteration
 template <bool DYN, bool LDS>
 void launchTrace(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity)
@@ -1255,8 +1308,7 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
     HIP_TRY(hipMemsetAsync(pools[0].cls, kClsEmpty, size_t(nSlots), stream));
     const uint64_t maxIters = (uint64_t(b.totalIds) / nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const bool dyn = sc->hasDynamic;
-    const bool lds = (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
-        && std::getenv("PT_NO_LDS_SCENE") == nullptr;
+    const bool lds = sceneFitsLds(sc);
     const uint32_t shadowCap = shadowCapOf(nSlots);
     const dim3 gridSlots(nSlots / 256u), block(256);
     // the first tracing launch has no generateKernel before it: nothing to add to the path numbers
@@ -1387,6 +1439,35 @@ int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out)
     for (uint64_t s = 0; s < ns; s++)
         for (uint64_t p = 0; p < npix; p++)
             std::memcpy(h_out + 3 * (p * ns + s), tmp.data() + 3 * (s * npix + p), 12);
+    return PT_OK;
+}
+
+// BVHTreeLinear::hit (reference src/15/bvh.hpp:183-213) of n rays in device memory with the renderer's own
+// bounds (amin 1e-4, amax FLT_MAX), through the tracing kernels a render of this scene uses.
+int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, const float* d_dirs, const float* d_times,
+                         pt_hit* d_out, hipStream_t stream)
+{
+    const uint64_t slotUnit = uint64_t(kClassifyRecords) * kShards;
+    const uint64_t nSlots = (n + slotUnit - 1) / slotUnit * slotUnit;
+    if (nSlots > (1ull << 31))
+        return fail(PT_ERR_LIMIT, "too many rays for one call");
+    int rc = ensureBuffers(scene, uint32_t(nSlots), 1, 1);
+    if (rc != PT_OK)
+        return rc;
+    WavefrontBuffers& w = scene->wf;
+    Pool pools[2];
+    carvePools(w.pool, uint32_t(nSlots), pools);
+    HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
+    // (no generateKernel ran: nothing to add to the path numbers, see runBatch)
+    for (uint32_t q = 0; q < kShards; q++)
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrLive + q) * kCtrStride),
+                                  int(nSlots / kShards), 1, stream));
+    hipLaunchKernelGGL(fillRaysKernel, dim3(uint32_t(nSlots / 256u)), dim3(256), 0, stream, pools[0], n, d_origins, d_dirs,
+                       d_times);
+    launchTraceFor(scene, pools[0], stream, 0, scene->hasDynamic, sceneFitsLds(scene));
+    hipLaunchKernelGGL(collectHitsKernel, dim3(uint32_t((n + 255u) / 256u)), dim3(256), 0, stream, scene->dev, pools[0], n,
+                       d_out);
+    HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 

@@ -3,7 +3,7 @@
 Bars: ids, flags and counters bit-exact; radiance bit-exact against the oracle evaluated with the
 same portable transcendentals; against vectors produced by the reference itself (C library
 transcendentals) within 1e-4 relative per sample, for all but a small stated fraction of samples
-whose paths branch differently after a one-ulp difference.
+whose paths branch differently after a one-ulp difference (1e-3 of the samples; none on the committed vectors).
 """
 import ctypes as C
 import os
@@ -16,8 +16,10 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 
-REL_TOL = 1e-4          # per-sample relative tolerance against reference-generated vectors
-OUTLIER_FRACTION = 0.02  # samples allowed to exceed it (paths that branch differently)
+REL_TOL = 1e-4           # per-sample relative tolerance against reference-generated vectors
+OUTLIER_FRACTION = 1e-3  # samples allowed to exceed it (paths that branch differently after a one-ulp difference
+                         # between the portable and the C library's transcendentals); measured on the committed
+                         # vectors: none, largest relative error 3.6e-5
 
 
 def bits(a):
@@ -127,10 +129,9 @@ def test_family_samples(name, golden_dir, oracle):
     assert hits.tobytes() == oracle.primary_hits(C.byref(d), cam, p, math_mode=1).tobytes()
     assert same_bits(got, want)
     golden = np.load(os.path.join(golden_dir, "family_%s_samples.npy" % name))
-    # the animated family evaluates a slerp (acos, sin) for every camera ray, so a larger share
-    # of its paths differs from the C-library evaluation by an ulp and then branches differently
-    limit = 0.10 if name == "animated" else OUTLIER_FRACTION
-    assert rel_outliers(got, golden) <= limit
+    # (the animated family evaluates a slerp per camera ray: a fifth of its samples differ from the C-library
+    # evaluation in some bit, none by more than the tolerance)
+    assert rel_outliers(got, golden) <= OUTLIER_FRACTION
 
 
 def test_materials_that_read_texture_coordinates_and_tangents(oracle):
