@@ -15,6 +15,7 @@ import pytest
 
 import path_tracing_amd as pt
 import scenes
+from hiprt import Hip
 
 pytestmark = pytest.mark.gpu
 
@@ -229,35 +230,6 @@ def test_rays_with_other_bounds_and_times(oracle):
         assert dev.trace_rays(o[:1], dirs[:1], t[:1]).tobytes() == oracle.trace_rays(C.byref(d), o[:1], dirs[:1], t[:1]).tobytes()
 
 
-class Hip:
-    """The few HIP runtime calls the test needs, from the runtime the library itself is linked with."""
-
-    def __init__(self):
-        self.rt = C.CDLL("libamdhip64.so")
-
-    def ok(self, rc):
-        assert rc == 0, "HIP error %d" % rc
-
-    def stream(self):
-        s = C.c_void_p()
-        self.ok(self.rt.hipStreamCreate(C.byref(s)))
-        return s
-
-    def zeros(self, nbytes):
-        p = C.c_void_p()
-        self.ok(self.rt.hipMalloc(C.byref(p), C.c_size_t(nbytes)))
-        self.ok(self.rt.hipMemset(p, 0, C.c_size_t(nbytes)))
-        return p
-
-    def to_host(self, p, shape):
-        out = np.empty(shape, np.float32)
-        self.ok(self.rt.hipMemcpy(out.ctypes.data_as(C.c_void_p), p, C.c_size_t(out.nbytes), 2))
-        return out
-
-    def sync(self):
-        self.ok(self.rt.hipDeviceSynchronize())
-
-
 def test_two_streams_and_two_threads_on_one_scene(golden_dir, oracle):
     """Two renders of one scene enqueued from two threads on two streams: the library orders them, and both
     images are the oracle's bit for bit."""
@@ -294,9 +266,9 @@ def test_two_streams_and_two_threads_on_one_scene(golden_dir, oracle):
                               (hip.to_host(out_c, (48, 64, 3)), want_b)):
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
             for p in (out_a, out_b, out_c):
-                hip.ok(hip.rt.hipFree(p))
-        hip.ok(hip.rt.hipStreamDestroy(sa))
-        hip.ok(hip.rt.hipStreamDestroy(sb))
+                hip.free(p)
+        hip.destroy_stream(sa)
+        hip.destroy_stream(sb)
 
 
 def test_scene_without_a_tree_refuses_to_render(oracle):
