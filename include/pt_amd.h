@@ -286,6 +286,28 @@ int pt_render(pt_scene* scene, const pt_camera* camera, const pt_render_params* 
 int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                      float* d_out_rgb, void* hip_stream);
 
+/* pt_render_device for callers that cannot allocate device memory (code under
+ * HIP graph capture set-up, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Same arguments, same image
+ * bit for bit; but the work areas of the renderer (path pools, queues,
+ * counters, sample buffer, running sums) are not allocated: they are carved
+ * from a 64 MiB device array that is part of the library's image, one copy
+ * per GPU, held until the process ends.  The call makes no hipMalloc /
+ * hipFree / hipHostMalloc and creates no events (per-kernel timing, see
+ * pt_scene_profile, is off during it).
+ * Limits: at most 524 288 pixels in the tile rectangle of one call
+ * (PT_ERR_LIMIT beyond; render larger images tile by tile), any number of
+ * samples (they are run in batches that fit the area).  The pools hold
+ * 131 072 paths, an eighth of what pt_render_device uses by default, so this
+ * entry point is slower on large renders.
+ * All calls on one GPU share that GPU's copy of the area.  Calls on the same
+ * scene are ordered by the library (see pt_scene_create).  Calls on different
+ * scenes of one GPU that overlap race on the area: the caller has to order
+ * them (same stream, or an event); a call that arrives while another call is
+ * still enqueueing on that GPU fails with PT_ERR_INVALID_ARGUMENT. */
+int pt_render_device_noalloc(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
+                             float* d_out_rgb, void* hip_stream);
+
 /* Closest hits of n caller-supplied rays: BVHTreeLinear::hit(ray, amin, amax)
  * (reference src/15/bvh.hpp:183-213) for each.  Host arrays: origins and
  * directions 3 floats per ray, times 1 per ray (may be NULL = 0). */

@@ -66,6 +66,8 @@ def lib():
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp]
         L.pt_render_device.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params),
                                        C.c_void_p, C.c_void_p]
+        L.pt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params),
+                                               C.c_void_p, C.c_void_p]
         L.pt_render_counted.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp,
                                         C.POINTER(abi.pt_counters)]
         L.pt_render_samples.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp]
@@ -573,6 +575,11 @@ class DeviceScene:
         """Asynchronous render into device memory (raw pointers: e.g. torch data_ptr / cuda_stream)."""
         _check(lib().pt_render_device(self.handle, C.byref(cam), C.byref(params), C.c_void_p(d_out_ptr),
                                       C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def render_device_noalloc(self, cam, params, d_out_ptr, stream_ptr=None):
+        """pt_render_device_noalloc: the same render from the fixed work area in the library's image."""
+        _check(lib().pt_render_device_noalloc(self.handle, C.byref(cam), C.byref(params), C.c_void_p(d_out_ptr),
+                                              C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.handle))

@@ -613,6 +613,9 @@ try {
     dev.n_surfaces = uint32_t(d->n_surfaces);
     dev.n_lights = uint32_t(d->n_lights);
     dev.envmap = d->envmap;
+    // (the address of this GPU's copy of the fixed work area, for pt_render_device_noalloc: looked up here, at
+    // set-up, so that the render call itself finds it in a table)
+    if ((rc = ptWavefrontStaticSetup(device)) != PT_OK) return bail(rc);
     if (hipEventCreate(&sc->evStart) != hipSuccess || hipEventCreate(&sc->evStop) != hipSuccess
         || hipEventCreateWithFlags(&sc->evDone, hipEventDisableTiming) != hipSuccess) {
         pt_scene_destroy(sc);
@@ -668,6 +671,21 @@ int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_p
     SceneCall call(scene, stream);
     HIP_TRY(call.status);
     rc = launchRender(scene, a, d_out_rgb, stream, nullptr);
+    HIP_TRY(call.done(stream));
+    return rc;
+}
+
+int pt_render_device_noalloc(pt_scene* scene, const pt_camera* camera, const pt_render_params* params, float* d_out_rgb,
+                             void* hip_stream)
+{
+    RenderArgs a;
+    int rc = checkRender(scene, camera, params, d_out_rgb, a);
+    if (rc != PT_OK)
+        return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    SceneCall call(scene, stream);
+    HIP_TRY(call.status);
+    rc = ptWavefrontRenderStatic(scene, a, d_out_rgb, stream);
     HIP_TRY(call.done(stream));
     return rc;
 }

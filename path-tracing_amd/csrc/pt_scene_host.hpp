@@ -69,6 +69,8 @@ struct WavefrontBuffers {
     uint64_t accumCapacity = 0; // in pixels
     uint32_t* counters = nullptr;
     uint32_t* hostCounters = nullptr; // pinned
+    bool fixed = false;      // the areas are parts of a fixed work area: never grown, never freed
+    uint32_t fixedSlots = 0; // records per pool that the fixed pool area holds
 };
 
 // Per-kernel device time of the wavefront renderer, measured with pairs of events on the
@@ -190,3 +192,6 @@ int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out_pixel_
 int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, const float* d_dirs, const float* d_times,
                          pt_hit* d_out, hipStream_t stream);
 void ptWavefrontRelease(pt_scene* scene);
+// the work area in the library's image on `device` (which must be current): looked up once per device
+int ptWavefrontStaticSetup(int device);
+int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "pt_scene_host.hpp"
@@ -1147,7 +1148,7 @@ uint64_t envU64(const char* name, uint64_t dflt)
 }
 
 // capacity of one shard's shadow queue: the slots of the blocks of that shard, rounded up to whole wave runs
-uint32_t shadowCapOf(uint32_t nSlots)
+constexpr uint32_t shadowCapOf(uint32_t nSlots)
 {
     const uint32_t blocks = nSlots / 256u;
     const uint32_t perShard = (blocks + kShards - 1) / kShards * 256u;
@@ -1156,7 +1157,7 @@ uint32_t shadowCapOf(uint32_t nSlots)
 }
 
 // waves of one tracing launch: whole blocks of slot waves, then whole blocks of shadow-queue waves
-void traceWavesOf(uint32_t nSlots, uint32_t& slotWaves, uint32_t& shadowWaves)
+constexpr void traceWavesOf(uint32_t nSlots, uint32_t& slotWaves, uint32_t& shadowWaves)
 {
     const uint32_t run = 64u * kItemsPerLane;
     slotWaves = ((nSlots + run - 1) / run + 3u) / 4u * 4u;
@@ -1164,14 +1165,14 @@ void traceWavesOf(uint32_t nSlots, uint32_t& slotWaves, uint32_t& shadowWaves)
 }
 
 // entries per retry sub-list: every wave of a tracing launch may put its whole run on its sub-list
-uint32_t retryCapOf(uint32_t nSlots)
+constexpr uint32_t retryCapOf(uint32_t nSlots)
 {
-    uint32_t slotWaves, shadowWaves;
+    uint32_t slotWaves = 0, shadowWaves = 0;
     traceWavesOf(nSlots, slotWaves, shadowWaves);
     return (slotWaves + shadowWaves + kRetryShards - 1) / kRetryShards * (64u * kItemsPerLane);
 }
 
-size_t poolBytes(uint32_t n)
+constexpr size_t poolBytes(uint32_t n)
 {
     return 2 * size_t(n) * (16 * 5 + 8 + 1) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 4)
         + size_t(retryCapOf(n)) * kRetryShards * 8;
@@ -1255,9 +1256,8 @@ bool sceneFitsLds(const pt_scene* sc)
 
 // the tracing step of one iteration
 template <bool DYN, bool LDS>
-void launchTrace(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity)
+void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_t stream, int parity)
 {
-    WavefrontBuffers& w = sc->wf;
     const dim3 block(256);
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
     uint32_t slotWaves, shadowWaves;
@@ -1285,22 +1285,21 @@ void launchTrace(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity)
     sc->kt.end(stream);
 }
 
-void launchTraceFor(pt_scene* sc, const Pool& pool, hipStream_t stream, int parity, bool dyn, bool lds)
+void launchTraceFor(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_t stream, int parity, bool dyn, bool lds)
 {
     if (dyn && lds)
-        launchTrace<true, true>(sc, pool, stream, parity);
+        launchTrace<true, true>(sc, w, pool, stream, parity);
     else if (dyn)
-        launchTrace<true, false>(sc, pool, stream, parity);
+        launchTrace<true, false>(sc, w, pool, stream, parity);
     else if (lds)
-        launchTrace<false, true>(sc, pool, stream, parity);
+        launchTrace<false, true>(sc, w, pool, stream, parity);
     else
-        launchTrace<false, false>(sc, pool, stream, parity);
+        launchTrace<false, false>(sc, w, pool, stream, parity);
 }
 
 // Run one batch of samples [b.sFirst, b.sFirst + b.nS) of every pixel of the tile into the sample buffer.
-int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools[2], hipStream_t stream)
+int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch& b, const Pool pools[2], hipStream_t stream)
 {
-    WavefrontBuffers& w = sc->wf;
     const uint32_t nSlots = pools[0].nSlots;
     HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(pools[0].d_s, 0, size_t(nSlots) * 16, stream)); // no paths yet
@@ -1325,7 +1324,7 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             const int parity = int(iter & 1);
             const Pool& cur = pools[iter & 1];
             const Pool& next = pools[(iter + 1) & 1];
-            launchTraceFor(sc, cur, stream, parity, dyn, lds);
+            launchTraceFor(sc, w, cur, stream, parity, dyn, lds);
             sc->kt.begin(KernelTimes::kClassify, stream);
             hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyRecords), dim3(kClassifyBlock), 0, stream, sc->dev, cur,
                                w.counters, w.samples);
@@ -1362,12 +1361,12 @@ int runBatch(pt_scene* sc, const RenderArgs& a, const Batch& b, const Pool pools
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
     // the last paths may have queued shadow rays in the very last shading launch: trace those
-    launchTraceFor(sc, pools[iter & 1], stream, int(iter & 1), dyn, lds);
+    launchTraceFor(sc, w, pools[iter & 1], stream, int(iter & 1), dyn, lds);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 
-int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t stream, bool keepSamples)
+int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float* d_out, hipStream_t stream, bool keepSamples)
 {
     const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
     const uint32_t nsTotal = uint32_t(a.s1 - a.s0);
@@ -1376,7 +1375,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     const uint32_t tilesX = uint32_t(a.tw + 7) / 8u, tilesY = uint32_t(a.th + 7) / 8u;
     const uint64_t idsPerSample = uint64_t(tilesX) * tilesY * 64u;
     // samples per batch: bounded by the sample-buffer budget and by 32-bit path numbers
-    const uint64_t budgetBytes = envU64("PT_SAMPLE_BUFFER_MB", 32768) << 20;
+    const uint64_t budgetBytes = w.fixed ? w.sampleCapacity * 12 : envU64("PT_SAMPLE_BUFFER_MB", 32768) << 20;
     uint64_t perBatch = std::max<uint64_t>(1, budgetBytes / (npix * 12));
     perBatch = std::min<uint64_t>(perBatch, (0xFFFFFFFFull - (1ull << 24)) / idsPerSample);
     if (perBatch == 0)
@@ -1384,13 +1383,20 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
     perBatch = std::min<uint64_t>(perBatch, nsTotal);
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    uint64_t nSlots = std::min<uint64_t>(envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
+    uint64_t nSlots = std::min<uint64_t>(w.fixed ? w.fixedSlots : envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
     const uint64_t slotUnit = uint64_t(kClassifyRecords) * kShards; // every shard's region and list is whole blocks
     nSlots = std::max<uint64_t>((nSlots + slotUnit - 1) / slotUnit * slotUnit, slotUnit);
-    int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
-    if (rc != PT_OK)
-        return rc;
-    WavefrontBuffers& w = sc->wf;
+    if (w.fixed) {
+        // work areas of a fixed size (nothing is allocated here): the caller has checked the pixel count
+        if (nSlots > w.fixedSlots || poolBytes(uint32_t(nSlots)) > w.poolCapacity || npix * perBatch > w.sampleCapacity
+            || npix > w.accumCapacity)
+            return fail(PT_ERR_LIMIT, "render does not fit the fixed work area");
+    } else {
+        int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
+        if (rc != PT_OK)
+            return rc;
+    }
+    int rc = PT_OK;
     Pool pools[2];
     carvePools(w.pool, uint32_t(nSlots), pools);
     HIP_TRY(hipEventRecord(sc->evStart, stream));
@@ -1402,7 +1408,7 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
         b.sFirst = uint32_t(a.s0) + s;
         b.npix = uint32_t(npix);
         b.totalIds = uint32_t(idsPerSample * b.nS);
-        rc = runBatch(sc, a, b, pools, stream);
+        rc = runBatch(sc, w, a, b, pools, stream);
         if (rc != PT_OK)
             return rc;
         if (d_out) {
@@ -1422,13 +1428,13 @@ int renderBatches(pt_scene* sc, const RenderArgs& a, float* d_out, hipStream_t s
 
 int ptWavefrontRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream)
 {
-    return renderBatches(scene, a, d_out, stream, false);
+    return renderBatches(scene, scene->wf, a, d_out, stream, false);
 }
 
 // Per-sample radiance in pixel-major, sample-minor order (host buffer).
 int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out)
 {
-    int rc = renderBatches(scene, a, nullptr, nullptr, true);
+    int rc = renderBatches(scene, scene->wf, a, nullptr, nullptr, true);
     if (rc != PT_OK)
         return rc;
     const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
@@ -1464,11 +1470,102 @@ int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, co
                                   int(nSlots / kShards), 1, stream));
     hipLaunchKernelGGL(fillRaysKernel, dim3(uint32_t(nSlots / 256u)), dim3(256), 0, stream, pools[0], n, d_origins, d_dirs,
                        d_times);
-    launchTraceFor(scene, pools[0], stream, 0, scene->hasDynamic, sceneFitsLds(scene));
+    launchTraceFor(scene, w, pools[0], stream, 0, scene->hasDynamic, sceneFitsLds(scene));
     hipLaunchKernelGGL(collectHitsKernel, dim3(uint32_t((n + 255u) / 256u)), dim3(256), 0, stream, scene->dev, pools[0], n,
                        d_out);
     HIP_TRY(hipGetLastError());
     return PT_OK;
+}
+
+// ---- rendering without allocating: a work area that is part of the library's image ----
+//
+// `scratch` is a device array in the code object, so every GPU the library runs on holds one copy
+// of it from the moment the code object is loaded there until the process ends.  Its layout is
+// fixed: path pools for kStaticSlots records, the counters, running sums for kStaticMaxPixels
+// pixels, and the rest as sample buffer.  In host code the name `scratch` is only a handle for
+// hipGetSymbolAddress: the address of the copy on a device is looked up once per device, with
+// that device current, and host code passes that pointer -- never the name -- to kernels and
+// memsets.  All calls on one GPU share the GPU's copy (they are serialised by `inUse`; a call
+// that finds the area taken fails rather than waits), and the area keeps the last call's
+// contents: runBatch clears what has to start at zero.
+constexpr uint32_t kStaticSlots = 2u * kClassifyRecords * kShards; // 131 072 records per pool
+constexpr uint64_t kStaticMaxPixels = 512u * 1024u;
+constexpr size_t kStaticBytes = size_t(64) << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+struct StaticArea {
+    unsigned char* ptr = nullptr; // this device's copy of `scratch`
+    bool inUse = false;
+    uint32_t hostCounters[kCtrWords]; // where the counters are read back to (ordinary host memory)
+};
+StaticArea g_static[kMaxDevices];
+std::mutex g_staticMutex;
+
+int ptWavefrontStaticSetup(int device)
+{
+    if (device < 0 || device >= kMaxDevices)
+        return fail(PT_ERR_LIMIT, "device number beyond the table of work areas");
+    std::lock_guard<std::mutex> lock(g_staticMutex);
+    if (g_static[device].ptr)
+        return PT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p || (reinterpret_cast<uintptr_t>(p) & 255u) != 0)
+        return fail(PT_ERR_DEVICE, "work area of the library image has no usable address on this GPU");
+    g_static[device].ptr = static_cast<unsigned char*>(p);
+    return PT_OK;
+}
+
+int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream)
+{
+    const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
+    if (npix > kStaticMaxPixels)
+        return fail(PT_ERR_LIMIT, "pt_render_device_noalloc renders at most 524288 pixels per call (use tile rectangles)");
+    const int device = scene->device;
+    int rc = ptWavefrontStaticSetup(device); // (a lookup in a table after the first call on this GPU)
+    if (rc != PT_OK)
+        return rc;
+    StaticArea& area = g_static[device];
+    {
+        std::lock_guard<std::mutex> lock(g_staticMutex);
+        if (area.inUse)
+            return fail(PT_ERR_INVALID_ARGUMENT, "the fixed work area of this GPU is in use by another call");
+        area.inUse = true;
+    }
+    // the parts of the area
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    WavefrontBuffers w;
+    w.fixed = true;
+    w.fixedSlots = kStaticSlots;
+    size_t off = 0;
+    w.pool = area.ptr;
+    w.poolCapacity = pad(poolBytes(kStaticSlots));
+    off += w.poolCapacity;
+    w.counters = reinterpret_cast<uint32_t*>(area.ptr + off);
+    off += pad(kCtrWords * sizeof(uint32_t));
+    w.accum = reinterpret_cast<float*>(area.ptr + off);
+    w.accumCapacity = kStaticMaxPixels;
+    off += pad(kStaticMaxPixels * 12);
+    w.samples = reinterpret_cast<float*>(area.ptr + off);
+    w.sampleCapacity = (kStaticBytes - off) / 12;
+    w.hostCounters = area.hostCounters;
+    static_assert((poolBytes(kStaticSlots) + 255) / 256 * 256 + (kCtrWords * 4 + 255) / 256 * 256 + 4 * kStaticMaxPixels * 12
+                      <= kStaticBytes,
+                  "the fixed work area holds the pools, the counters, the sums and at least three samples per pixel");
+    // (no per-kernel event timing here: its events are created on demand)
+    const bool timing = scene->kt.enabled;
+    scene->kt.enabled = false;
+    rc = renderBatches(scene, w, a, d_out, stream, false);
+    scene->kt.enabled = timing;
+    // the area is free for the next call once this call's kernels have run: later calls are ordered behind them by
+    // the scene's event when they use this scene; calls through another scene of this GPU have to be ordered by the
+    // caller (same stream, or an event of its own)
+    {
+        std::lock_guard<std::mutex> lock(g_staticMutex);
+        area.inUse = false;
+    }
+    return rc;
 }
 
 void ptWavefrontRelease(pt_scene* scene)
