@@ -1,25 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X render loop: path samples / s at 1080p.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload cornell|mesh1000|textured|frames]
 
-One step = one full render of the workload (all pixels, all samples) on every
-rank.  N = 1 renders the Cornell box with glossy (Phong) boxes and MIS at
-1920x1080, 1024 spp -- the configuration the metric is quoted on.  With N > 1
-(launched one process per GPU by torch.distributed.run) every rank renders its
-own 1024-spp batch of the same frame (rank-specific seed: weak scaling) and the
-float sum buffers are combined on rank 0 with one RCCL reduce inside the timed
-region.  Rank 0 prints one JSON line.
+One step = one full render of the workload (all pixels, all samples; `frames`: a set of frames).  N = 1 renders
+the Cornell box with glossy (Phong) boxes and MIS at 1920x1080, 1024 spp -- the configuration the metric is quoted
+on.  With N > 1 (one process per GPU, launched by torch.distributed.run) the SAME work is split over the ranks
+(strong scaling): disjoint sample ranges of the same 1024 spp (cornell, mesh), image tiles (textured), or whole
+frames with the frames left over split by samples (frames); the float buffers are combined on rank 0 with one RCCL
+sum-reduce inside the timed region.  Rank 0 prints one JSON line.
 
 The line also carries
-  roofline      algorithmic bytes of the reference algorithm (per-sample counts
-                measured by the instrumented kernel on the same scene) divided
-                by the kernel's duration from HIP events on the launch stream,
-                against the HBM peak; and the same for FP32 vector flops,
-  cpu_baseline  the compiled reference (oracle/_ref/libpt_ref_fast.so: the
-                reference's own pathSample / BVH / material code with its
-                shipped optimisation level) timed on this machine's host cores
-                on a reduced-spp render of the same scene.
+  roofline      for the kernel with the most device time: what it achieves against the limit that binds it.
+                Scenes whose tables fit LDS: FP32 vector flops of the walk (30 per box test, 60 per surface test,
+                counted by the instrumented kernel) over the kernel's duration against the FP32 vector peak.
+                Scenes in memory: bytes the executed walk has to move (32 per box row, 48 per surface test, the
+                ray records in and out; counted by the instrumented kernel) over the duration against the HBM peak,
+                beside the HBM bytes rocprofv3's counters saw for the same launch (profiles/).
+  rmse          the rendered image, averaged over 20x20 pixel blocks, against a converged 96x54 image of the same
+                view rendered by the reference with its own generator (tests/golden/converged_*.npz).
+  cpu_baseline  the compiled reference (oracle/_ref/libpt_ref_fast.so: the reference's own pathSample / BVH /
+                material code at its shipped optimisation level) timed on this machine's host cores on a
+                reduced-spp render of the same scene, median of three.
 """
 import argparse
 import ctypes as C
@@ -31,50 +33,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # HBM3E peak, GB/s
-VALU_PEAK_TFLOPS = 157.3     # FP32 vector peak, TFLOP/s
+HBM_PEAK_GBS = 8000.0            # HBM3E peak, GB/s
+VALU_PEAK_TFLOPS = 157.3         # FP32 vector peak with fused multiply-add, TFLOP/s
+VALU_PEAK_UNFUSED_TFLOPS = 78.6  # the same issue rate without fusing: this code is built with contraction off
 
-
-def workload(name):
-    """(scene, camera, label, sqrt_spp, extra): extra may hold width, height, samples (a range of the
-    sqrt_spp^2 strata), max_path_segments, frames (list of shutter intervals, one render each per step)
-    and the sharding mode for more than one GPU."""
-    import path_tracing_amd as pt
-    golden = os.path.join(ROOT, "tests", "golden")
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    if name == "cornell":
-        scene = pt.LoadedScene(os.path.join(golden, "cornell_glossy.ptscene"))
-        cam = pt.load_camera(os.path.join(golden, "cornell_wide.ptcam"))
-        return scene, cam, "cornell-box glossy+MIS 1920x1080 1024spp (BASELINE configs[1])", 32, {}
-    if name.startswith("mesh"):
-        import scenes
-        n = int(name[4:] or 1000)
-        s, cam = scenes.big_mesh_scene(n)
-        return s, cam, "displaced grid %d triangles 1920x1080 256spp (BASELINE configs[2])" % (2 * n * n + 2), 16, {}
-    if name == "textured":
-        # every material, image/checker/transformer textures, normal and opacity maps, image environment map
-        import scenes
-        s, cam, _ = scenes.build("materials")
-        return s, cam, "textured multi-material 3840x2160 512spp max depth 32 (BASELINE configs[3])", 23, {
-            "width": 3840, "height": 2160, "samples": (0, 512), "max_path_segments": 32, "sharding": "tiles"}
-    if name == "frames":
-        # two-key animated spheres, meshes, lights and camera; a new tree per frame (shutter 1/25 s)
-        import scenes
-        s, cam, _ = scenes.build("animated")
-        frames = [(f / 25.0, (f + 1) / 25.0) for f in range(8)]
-        return s, cam, "animated scene, 8 of 240 frames per step, 1920x1080 128spp (BASELINE configs[4])", 12, {
-            "samples": (0, 128), "frames": frames, "sharding": "frames"}
-    raise SystemExit("unknown workload " + name)
-
-
-def algorithmic_per_sample(cnt, n_lights):
-    """Bytes and flops per path sample of the reference algorithm, from measured work counts:
-    32 B per node visit, 48 B per leaf primitive test, 48 B per light-pdf primitive test, 12 B of
-    output; ~30 flops per slab test, ~60 per primitive test, ~300 per shaded vertex."""
-    n = max(cnt["path_samples"], 1)
-    bytes_ = (cnt["node_visits"] * 32 + cnt["leaf_tests"] * 48 + cnt["light_tests"] * 48) / n + 12
-    flops = (cnt["node_visits"] * 30 + (cnt["leaf_tests"] + cnt["light_tests"]) * 60 + cnt["vertices"] * 300) / n
-    return bytes_, flops
+TRACE_KERNELS = ("traceKernel", "traceOrderedKernel", "traceRetryKernel")
 
 
 def measured_traffic(workload_name, kernel):
@@ -88,19 +51,13 @@ def measured_traffic(workload_name, kernel):
     with open(path) as f:
         t = json.load(f)
     ks = t.get("kernels", {})
-    if kernel == "traceKernel":
-        # one tracing step of the renderer is one launch of traceKernel (scenes held in LDS), or a launch of
-        # traceOrderedKernel followed by one of traceRetryKernel (scenes in memory)
-        rows = [v for name, v in ks.items() if name.startswith("trace")]
-    else:
-        rows = [ks[kernel]] if kernel in ks else []
-    if not rows:
+    if kernel not in ks:
         return None, "PMC file has no row for " + kernel
-    return sum(r["hbm_bytes_per_launch"] for r in rows), t.get("how", "")
+    return ks[kernel]["hbm_bytes_per_launch"], t.get("how", "")
 
 
-def cpu_baseline(scene, cam, width, height, seed):
-    """Time the compiled reference on the host cores on a bounded sample of the workload."""
+def cpu_baseline(scene, cam, width, height, seed, t0=0.0, t1=0.0):
+    """Time the compiled reference on the host cores on a bounded sample of the workload: median of three."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import refbind
     import path_tracing_amd as pt
@@ -114,22 +71,52 @@ def cpu_baseline(scene, cam, width, height, seed):
     saved = os.dup(2)
     os.dup2(devnull, 2)  # the reference prints progress on stderr
     try:
-        rs = R.scene(C.byref(d))
-        # calibrate on 1 spp, then pick sqrt_spp for roughly 15 s
-        p = pt.make_params(width, height, 1, seed=seed)
-        _, t1 = rs.render(cam, p, rng_mode=1, threads=threads)
-        rate = width * height / max(t1, 1e-6)
-        sqrt_spp = max(1, min(8, int((15.0 * rate / (width * height)) ** 0.5)))
-        p = pt.make_params(width, height, sqrt_spp, seed=seed)
-        _, secs = rs.render(cam, p, rng_mode=1, threads=threads)
+        rs = R.scene(C.byref(d), t0, t1)
+        # calibrate on 1 spp, then pick sqrt_spp for roughly 7 s per run
+        p = pt.make_params(width, height, 1, seed=seed, t0=t0, t1=t1)
+        _, t_one = rs.render(cam, p, rng_mode=1, threads=threads)
+        rate = width * height / max(t_one, 1e-6)
+        sqrt_spp = max(1, min(8, int((7.0 * rate / (width * height)) ** 0.5)))
+        p = pt.make_params(width, height, sqrt_spp, seed=seed, t0=t0, t1=t1)
+        runs = sorted(rs.render(cam, p, rng_mode=1, threads=threads)[1] for _ in range(3))
     finally:
         os.dup2(saved, 2)
         os.close(devnull)
         os.close(saved)
     n = width * height * sqrt_spp * sqrt_spp
-    return {"value": n / secs, "unit": "path samples/s", "cores": threads, "kind": "reference",
-            "sample": "%dx%d at %d spp (%d path samples, %.1f s), reference's own generator, "
-                      "g++ -Ofast -march=x86-64-v3 -fopenmp" % (width, height, sqrt_spp * sqrt_spp, n, secs)}
+    return {"value": n / runs[1], "unit": "path samples/s", "cores": threads, "kind": "reference",
+            "runs_s": runs,
+            "sample": "%dx%d at %d spp (%d path samples), median of 3 runs (%.1f s), reference's own generator, "
+                      "g++ -Ofast -march=x86-64-v3 -fopenmp" % (width, height, sqrt_spp * sqrt_spp, n, runs[1])}
+
+
+def block_average(img, bh, bw):
+    h, w, _ = img.shape
+    return img.reshape(h // bh, bh, w // bw, bw, 3).mean(axis=(1, 3))
+
+
+def rmse_against_converged(img, path, spp):
+    """RMSE of the block-averaged image against the converged reference image of the same view.  A pixel of the
+    small image integrates over exactly the area of its block of pixels of the large one (the camera maps image
+    fractions to directions), so the two estimate the same quantity; what is left is the noise of both.  Bound:
+    1.5 x the RMS noise expected from the two sample counts."""
+    import numpy as np
+    if not path or not os.path.exists(path):
+        return None
+    z = np.load(path)
+    ref = z["image"]
+    h, w, _ = img.shape
+    if h % ref.shape[0] or w % ref.shape[1]:
+        return None
+    bh, bw = h // ref.shape[0], w // ref.shape[1]
+    small = block_average(img.astype(np.float64), bh, bw)
+    rmse = float(np.sqrt(np.mean((small - ref) ** 2)))
+    noise, ref_spp = float(z["noise_rmse"]), int(z["spp"])
+    expected = noise * (1.0 + ref_spp / float(spp * bh * bw)) ** 0.5
+    return {"value": rmse, "bound": 1.5 * expected, "within_bound": bool(rmse <= 1.5 * expected),
+            "relative_to_mean": rmse / max(float(ref.mean()), 1e-12),
+            "reference": "%s: reference's pathSample with its own generator, %d spp at %dx%d, noise rmse %.3g; image "
+                         "averaged over %dx%d blocks" % (os.path.basename(path), ref_spp, ref.shape[1], ref.shape[0], noise, bw, bh)}
 
 
 def main():
@@ -145,17 +132,23 @@ def main():
     ap.add_argument("--bvh", choices=["host", "device"], default="host",
                     help="host: the reference's tree (pt_bvh_build); device: the tree built by pt_scene_build_bvh_device")
     args = ap.parse_args()
-    if os.environ.get("PT_BENCH_WATCHDOG"):
-        # where every thread stands, should a run stop making progress
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["PT_BENCH_WATCHDOG"]), exit=False, file=sys.stderr)
 
+    rank = int(os.environ.get("RANK", "0"))
+    # where every thread stands, should a run stop making progress: written to gpurun_out/, kept only if it trips
+    import faulthandler
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    watchdog_path = os.path.join(ROOT, "gpurun_out", "bench_watchdog_rank%d.log" % rank)
+    watchdog_file = open(watchdog_path, "w")
+    faulthandler.dump_traceback_later(int(os.environ.get("PT_BENCH_WATCHDOG", "240")), repeat=True, exit=False,
+                                      file=watchdog_file)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import path_tracing_amd as pt
-    from path_tracing_amd import abi
+    from path_tracing_amd import workloads
+    from path_tracing_amd import distributed as shard
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal on a one-GPU machine: PT_BENCH_REHEARSAL=1 puts every rank on GPU 0 and exchanges over gloo
     rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
@@ -177,13 +170,15 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    scene, cam, label, default_sqrt, extra = workload(args.workload)
+    scene, cam, label, default_sqrt, extra = workloads.load(args.workload)
     sqrt_spp = args.sqrt_spp or default_sqrt
     W, H = extra.get("width", args.width), extra.get("height", args.height)
     samples = extra.get("samples") if not args.sqrt_spp else None
-    spp = (samples[1] - samples[0]) if samples else sqrt_spp * sqrt_spp
+    s_begin, s_end = samples if samples else (0, sqrt_spp * sqrt_spp)
+    spp = s_end - s_begin
     frames = extra.get("frames")
-    mode = extra.get("sharding", "batches")
+    mode = extra.get("sharding", "samples")
+    max_seg = extra.get("max_path_segments", 0)
     dev = pt.DeviceScene(scene, device=local_rank)
     bvh_build_ms = None
     if args.bvh == "device":
@@ -195,52 +190,81 @@ def main():
         bvh_build_ms = (time.perf_counter() - tb) * 1e3
     out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
-    # every rank renders its own batch of samples of the same frame (its own seed)
-    params = pt.make_params(W, H, sqrt_spp, seed=42, samples=samples,
-                            max_path_segments=extra.get("max_path_segments", 0))
-
-    from path_tracing_amd import distributed as shard
+    # a range of the strata (512 of 23 x 23): the library's mean is over all sqrt_spp^2 strata, so take plain sums and
+    # divide by the number of samples rendered
+    partial = samples is not None and spp != sqrt_spp * sqrt_spp
+    params = pt.make_params(W, H, sqrt_spp, seed=42, samples=samples, max_path_segments=max_seg,
+                            flags=pt.abi.PT_RENDER_SUM_ONLY if partial else 0)
     events = []
 
     def render(p, buf):
         dev.render_device(cam, p, buf.data_ptr(), stream.cuda_stream)
+
+    def reduce_to_root(buf):
+        if rehearsal:
+            # gloo, ranks sharing one GPU: reduce a host copy
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        else:
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+
+    def frame_tree(t0f, t1f):
+        if args.bvh == "device":
+            dev.build_bvh_device(t0f, t1f, stream.cuda_stream)
+        else:
+            dev.update_bvh(scene.build_bvh(t0f, t1f) if hasattr(scene, "build_bvh") else host_tree(t0f, t1f))
+
+    flat_for_trees = []
+
+    def host_tree(t0f, t1f):
+        # (a scene file is read-only: the reference's builder runs on a copy of its tables)
+        if not flat_for_trees:
+            flat_for_trees.append(pt.FlatScene.from_desc(scene.desc()))
+        return flat_for_trees[0].build_bvh(t0f, t1f)
 
     def step(timed=False):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
         if frames:
-            # this rank's frames, round robin: tree over the frame's shutter interval (host builder),
-            # upload, render; no exchange
-            for f in shard.plan_frames(len(frames), world, rank):
+            # whole frames round robin, no exchange; the frames left over when the count is no multiple of the
+            # ranks are rendered by all ranks together, each its own sample range, and summed on rank 0
+            for f, srange in shard.plan_frames_and_samples(len(frames), spp, world, rank):
                 t0f, t1f = frames[f]
-                if args.bvh == "device":
-                    dev.build_bvh_device(t0f, t1f, stream.cuda_stream)
+                frame_tree(t0f, t1f)
+                if srange is None:
+                    render(pt.make_params(W, H, sqrt_spp, seed=42 + f, t0=t0f, t1=t1f, samples=samples,
+                                          flags=pt.abi.PT_RENDER_SUM_ONLY if partial else 0), out)
+                    if partial:
+                        out.div_(float(spp))
                 else:
-                    dev.update_bvh(scene.build_bvh(t0f, t1f))
-                render(pt.make_params(W, H, sqrt_spp, seed=42 + f, t0=t0f, t1=t1f, samples=samples), out)
+                    b, e = s_begin + srange[0], s_begin + srange[1]
+                    if e > b:
+                        render(pt.make_params(W, H, sqrt_spp, seed=42 + f, t0=t0f, t1=t1f, samples=(b, e),
+                                              flags=pt.abi.PT_RENDER_SUM_ONLY), out)
+                    else:
+                        out.zero_()
+                    reduce_to_root(out)
+                    if rank == 0:
+                        out.div_(float(spp))
         elif world == 1:
             render(params, out)
+            if partial:
+                out.div_(float(spp))
         else:
-            # this rank's share (its own batch of samples, or its tiles), then one RCCL sum-reduce to rank 0
+            # this rank's share (its sample range, or its tiles), then one sum-reduce to rank 0
             if mode == "tiles":
                 out.zero_()
-            for p in shard.shard_params(params, mode, world, rank, tile=512):
+            for p in shard.shard_params(params, mode, world, rank, tile=256):
                 render(p, out)
         if timed:
             e1.record(stream)
             events.append((e0, e1))
         if world > 1 and not frames:
-            if rehearsal:
-                # gloo, ranks sharing one GPU: reduce a host copy (gloo's own staging of device tensors was seen
-                # to stall now and then when two processes share a device)
-                host = out.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                out.copy_(host)
-            else:
-                dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0 and mode == "batches":
-                out.div_(float(spp * world))
+            reduce_to_root(out)
+            if rank == 0 and (mode == "samples" or partial):
+                out.div_(float(spp))
 
     def barrier():
         if world > 1:
@@ -258,90 +282,162 @@ def main():
         step(timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
-    # duration of the whole launch sequence of one render: HIP events on the launch stream
+    # duration of the whole launch sequence of one step on this rank: HIP events on the launch stream
     last_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / len(events)
     kernel_times = dev.kernel_times() if rank == 0 else {}
     dev.profile(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     result = None
     if rank == 0:
-        n_renders = len(frames) if frames else (world if mode == "batches" else 1)
+        n_renders = len(frames) if frames else 1
         total_samples = float(W) * H * spp * n_renders * args.steps
         value = total_samples / elapsed
-        # work counts of the reference algorithm on this scene (instrumented kernel, reduced spp)
-        cparams = pt.make_params(W // 4, H // 4, min(sqrt_spp, 4), seed=42)
+        image = out.cpu().numpy()
+        # what fraction of the step's samples this rank's kernels advanced
+        if frames:
+            plan = shard.plan_frames_and_samples(len(frames), spp, world, 0)
+            rank_samples = float(W) * H * sum(spp if sr is None else sr[1] - sr[0] for _, sr in plan)
+        else:
+            rank_samples = float(W) * H * spp / world
+
+        # work counts of the reference algorithm on this scene (instrumented megakernel, reduced size) and of the
+        # walk the tracing kernels execute (instrumented tracing kernels, same reduced render)
+        tf0, tf1 = frames[0] if frames else (0.0, 0.0)
+        if frames:
+            frame_tree(tf0, tf1)
+        cparams = pt.make_params(W // 4, H // 4, min(sqrt_spp, 4), seed=42, t0=tf0, t1=tf1, max_path_segments=max_seg)
         _, cnt = dev.render_counted(cam, cparams)
         cnt = cnt.as_dict()
-        bytes_ps, flops_ps = algorithmic_per_sample(cnt, 0)
-        launch_samples = float(W) * H * spp * (len(shard.plan_frames(len(frames), world, 0)) if frames else 1)
-        if world > 1 and mode == "tiles":
-            launch_samples /= world
-        n_s = max(cnt["path_samples"], 1)
-        # the reference algorithm's bytes, split by the kernel that does that part of the work
-        kernel_bytes_ps = {
-            "traceKernel": (cnt["node_visits"] * 32 + cnt["leaf_tests"] * 48) / n_s,
-            "shadeHitsKernel": cnt["light_tests"] * 48 / n_s + 12,
+        n_s = float(max(cnt["path_samples"], 1))
+        dev.count_walk(True)
+        dev.render(cam, cparams)
+        walk = dev.walk_counters()
+        dev.count_walk(False)
+        ref_per_sample = {k: cnt[k] / n_s for k in cnt if k != "path_samples"}
+        walk_per_sample = {k: walk[k] / n_s for k in walk}
+
+        # per launch of the tracing step: bytes the executed walk has to move, and its vector flops
+        first_pass_rays = walk_per_sample["path_rays"] + walk_per_sample["shadow_rays"]
+        per_sample = {
+            "traceKernel": {
+                "bytes": 32 * walk_per_sample["box_rows"] + 48 * walk_per_sample["surface_tests"]
+                         + 49 * walk_per_sample["path_rays"] + 64 * walk_per_sample["shadow_rays"],
+                "flops": 30 * walk_per_sample["box_rows"] + 60 * walk_per_sample["surface_tests"]},
+            "traceOrderedKernel": {
+                "bytes": 32 * (walk_per_sample["box_rows"] + walk_per_sample["leaf_rows"]) + 48 * walk_per_sample["surface_tests"]
+                         + 49 * walk_per_sample["path_rays"] + 64 * walk_per_sample["shadow_rays"],
+                # a row of the nearer-child-first walk is two box tests (30 each) and 24 flops of decoding
+                "flops": 84 * walk_per_sample["box_rows"] + 30 * walk_per_sample["leaf_rows"] + 60 * walk_per_sample["surface_tests"]},
+            "traceRetryKernel": {
+                "bytes": 32 * walk_per_sample["retry_node_visits"] + 48 * walk_per_sample["retry_surface_tests"]
+                         + 57 * walk_per_sample["retry_rays"],
+                "flops": 30 * walk_per_sample["retry_node_visits"] + 60 * walk_per_sample["retry_surface_tests"]},
+            "shadeHitsKernel": {
+                # per shaded vertex: the path record in (88 bytes) and out (72), the surface's rows and attributes (64+)
+                # and a shadow-queue entry (48); per light-pdf test a 48-byte surface row; 12 bytes per finished sample
+                "bytes": ref_per_sample["vertices"] * (88 + 72 + 64 + 48) + 48 * ref_per_sample["light_tests"] + 12,
+                "flops": 300 * ref_per_sample["vertices"] + 60 * ref_per_sample["light_tests"]},
         }
+        in_lds = kernel_times.get("traceKernel", (0, 0))[0] > 0 and kernel_times.get("traceOrderedKernel", (0, 0))[0] == 0 \
+            and (2 * scene.desc().n_bvh_nodes + 3 * scene.desc().n_surfaces) * 16 <= 16384
+        if in_lds:
+            # node and surface rows are read from the copy in LDS: only the ray records cross the memory system
+            per_sample["traceKernel"]["lds_bytes"] = 32 * walk_per_sample["box_rows"] + 48 * walk_per_sample["surface_tests"]
+            per_sample["traceKernel"]["bytes"] -= per_sample["traceKernel"]["lds_bytes"]
         kernels = {}
         for name, (launches, total_ms) in kernel_times.items():
-            if launches:
-                kernels[name] = {"launches_per_step": launches / args.steps, "avg_us": total_ms / launches * 1e3,
-                                 "ms_per_step": total_ms / args.steps}
-                if name in kernel_bytes_ps:
-                    per_launch = launch_samples * args.steps / launches
-                    kernels[name]["algorithmic_GBps"] = kernel_bytes_ps[name] * per_launch / (total_ms / launches * 1e-3) / 1e9
-                    kernels[name]["hbm_bytes_per_launch"] = measured_traffic(args.workload, name)[0]
-        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+            if not launches:
+                continue
+            k = {"launches_per_step": launches / args.steps, "avg_us": total_ms / launches * 1e3,
+                 "ms_per_step": total_ms / args.steps}
+            if name in per_sample:
+                samples_per_launch = rank_samples * args.steps / launches
+                secs = total_ms / launches * 1e-3
+                k["samples_per_launch"] = samples_per_launch
+                k["algorithmic_GBps"] = per_sample[name]["bytes"] * samples_per_launch / secs / 1e9
+                k["algorithmic_TFLOPs"] = per_sample[name]["flops"] * samples_per_launch / secs / 1e12
+                traffic = measured_traffic(args.workload, name)[0] if args.bvh == "host" else None
+                k["hbm_bytes_per_launch"] = traffic
+                if traffic:
+                    k["hbm_GBps"] = traffic / secs / 1e9
+            kernels[name] = k
+        dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
         dk = kernels[dominant]
-        # one launch of the dominant kernel advances (samples of a render / its launches per render) samples
-        samples_per_launch = launch_samples / dk["launches_per_step"]
-        ach_gbs = kernel_bytes_ps.get(dominant, bytes_ps) * samples_per_launch / (dk["avg_us"] * 1e-6) / 1e9
-        # vector flops are priced over the whole launch sequence (they are spread over all kernels)
-        ach_tf = flops_ps * launch_samples / (last_ms * 1e-3) / 1e12
         traffic, traffic_note = measured_traffic(args.workload, dominant)
         if args.bvh == "device":
             traffic, traffic_note = None, "the committed PMC passes were taken with the reference's tree"
+        alg_bytes_launch = per_sample.get(dominant, {"bytes": 0})["bytes"] * dk.get("samples_per_launch", 0)
+        common = {"kernel": dominant, "kernel_avg_us": dk["avg_us"], "kernel_launches_per_step": dk["launches_per_step"],
+                  "samples_per_launch": dk.get("samples_per_launch"), "traffic": traffic, "traffic_note": traffic_note,
+                  "algorithmic_bytes_per_launch": alg_bytes_launch,
+                  "traffic_over_algorithmic": (traffic / alg_bytes_launch) if traffic and alg_bytes_launch else None}
+        if in_lds:
+            # node and surface tables are in LDS: the walk never touches HBM, what binds is vector issue
+            ach = dk.get("algorithmic_TFLOPs", 0.0)
+            roofline = dict(common, bound="fp32-valu", achieved=ach, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=ach / VALU_PEAK_TFLOPS, peak_unfused=VALU_PEAK_UNFUSED_TFLOPS,
+                            frac_unfused=ach / VALU_PEAK_UNFUSED_TFLOPS,
+                            flops_per_sample=per_sample.get(dominant, {}).get("flops"),
+                            hbm_frac=(dk["hbm_GBps"] / HBM_PEAK_GBS) if dk.get("hbm_GBps") else None,
+                            note="scene tables (%d bytes) are held in LDS; flops = 30 per box test + 60 per surface test of "
+                                 "the executed walk (instrumented kernel), no fused multiply-add (contraction is off for "
+                                 "bit-reproducible results), so 78.6 TFLOP/s is the issue limit of this code; `traffic` is "
+                                 "path-state traffic" % ((2 * scene.desc().n_bvh_nodes + 3 * scene.desc().n_surfaces) * 16))
+        else:
+            ach = dk.get("algorithmic_GBps", 0.0)
+            roofline = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                            traffic_GBps=dk.get("hbm_GBps"),
+                            traffic_frac=(dk["hbm_GBps"] / HBM_PEAK_GBS) if dk.get("hbm_GBps") else None,
+                            bytes_per_sample=per_sample.get(dominant, {}).get("bytes"),
+                            note="achieved = bytes the executed walk has to move (32 per box row, 48 per surface test, ray "
+                                 "records in and out; counts from the instrumented kernel) / kernel duration; `traffic` = "
+                                 "HBM bytes per launch from rocprofv3 counters (profiles/)")
+        # all kernels of one step together against both limits
+        total_flops = sum(per_sample[n]["flops"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
+                          for n in kernels if n in per_sample)
+        total_bytes = sum(per_sample[n]["bytes"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
+                          for n in kernels if n in per_sample)
+        whole = {"ms": last_ms,
+                 "valu_TFLOPs": total_flops / (last_ms * 1e-3) / 1e12, "valu_frac": total_flops / (last_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                 "valu_frac_unfused": total_flops / (last_ms * 1e-3) / 1e12 / VALU_PEAK_UNFUSED_TFLOPS,
+                 "algorithmic_GBps": total_bytes / (last_ms * 1e-3) / 1e9, "hbm_frac": total_bytes / (last_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+        shard_text = {"samples": "disjoint sample ranges of the same %d spp per GPU, one sum-reduce to rank 0" % spp,
+                      "tiles": "256x256 tiles interleaved over GPUs, one sum-reduce to rank 0",
+                      "frames": "frames round robin over GPUs, no exchange; frames left over split by sample range "
+                                "and sum-reduced"}[mode if not frames else "frames"]
         result = {
             "metric": "path samples/sec at 1080p", "value": value, "unit": "path samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if mode == "batches" else "strong",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "spp": spp, "bvh": args.bvh, "bvh_build_ms": bvh_build_ms,
                        "samples_per_step": total_samples / args.steps,
-                       "sharding": "single GPU" if world == 1 else
-                       {"batches": "one %d-spp batch per GPU (rank-specific seed), RCCL sum-reduce to rank 0" % spp,
-                        "tiles": "512x512 tiles interleaved over GPUs, RCCL sum-reduce to rank 0",
-                        "frames": "frames round robin over GPUs, no exchange"}[mode]},
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dominant, "kernel_avg_us": dk["avg_us"],
-                         "kernel_launches_per_step": dk["launches_per_step"],
-                         "samples_per_launch": samples_per_launch,
-                         "algorithmic_bytes_per_sample": kernel_bytes_ps.get(dominant, bytes_ps),
-                         "traffic_note": traffic_note,
-                         "note": "algorithmic bytes = 32 B per node visit + 48 B per primitive test of the reference "
-                                 "algorithm for the rays this kernel traces (work counts measured on this scene); a "
-                                 "scene whose tables fit LDS or cache is bound by vector ALU issue instead, see "
-                                 "roofline_valu"},
-            "roofline_valu": {"bound": "fp32-valu", "achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach_tf / VALU_PEAK_TFLOPS, "algorithmic_flops_per_sample": flops_ps,
-                              "over": "all kernels of one render (%.1f ms)" % last_ms},
+                       "sharding": "single GPU" if world == 1 else shard_text},
+            "rays_per_s": value * ref_per_sample["rays"],
+            "rmse": rmse_against_converged(image, extra.get("converged"), spp) if not args.sqrt_spp else None,
+            "roofline": roofline,
+            "whole_step": whole,
             "kernels": kernels,
-            "work_per_sample": {k: cnt[k] / max(cnt["path_samples"], 1) for k in cnt if k != "path_samples"},
+            "work_per_sample": ref_per_sample,
+            "executed_walk_per_sample": walk_per_sample,
         }
         if not args.no_cpu_baseline and world == 1:
-            base = cpu_baseline(scene, cam, W, H, 42)
+            base = cpu_baseline(scene, cam, W, H, 42, tf0, tf1)
             if base is not None:
                 result["cpu_baseline"] = base
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+    watchdog_file.close()
+    if os.path.getsize(watchdog_path) == 0:
+        os.remove(watchdog_path)
     if rank == 0:
         print(json.dumps(result))
 

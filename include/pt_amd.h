@@ -352,6 +352,31 @@ typedef struct pt_kernel_time {
 int pt_scene_profile(pt_scene* scene, int enable);
 int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, int* count);
 
+/* Work of the walk the tracing kernels actually execute -- which for scenes
+ * held in memory is not the reference's storage-order walk (pt_counters counts
+ * that one) but a nearer-child-first walk plus a storage-order second pass for
+ * the rays it leaves open.  The reference has no counterpart.  These sums
+ * price a tracing kernel against the memory system: every box row is 32 bytes,
+ * every surface test 48 bytes of surface rows.  pt_scene_count_walk(scene, 1)
+ * clears the sums and makes the following pt_render* / pt_trace_rays calls
+ * launch instrumented builds of the tracing kernels (slower; same results),
+ * (scene, 0) goes back to the plain ones; pt_scene_walk_counters waits for the
+ * scene's work and reads the sums. */
+typedef struct pt_walk_counters {
+    uint64_t path_rays;            /* rays of paths traced by the first pass */
+    uint64_t shadow_rays;          /* queued shadow rays traced by the first pass */
+    uint64_t box_rows;             /* 32-byte rows fetched for box tests: one node (storage-order walk) or both
+                                      children of an inner node on a 16-bit grid (nearer-child-first walk) */
+    uint64_t leaf_rows;            /* nearer-child-first walk: exact leaf boxes read from the node table, 32 bytes */
+    uint64_t surface_tests;        /* triangle / sphere rows fetched and tested, 48 bytes */
+    uint64_t retry_rays;           /* rays handed to the storage-order second pass */
+    uint64_t retry_node_visits;    /* its node visits, 32 bytes each */
+    uint64_t retry_surface_tests;  /* its surface tests, 48 bytes each */
+} pt_walk_counters;
+
+int pt_scene_count_walk(pt_scene* scene, int enable);
+int pt_scene_walk_counters(pt_scene* scene, pt_walk_counters* out);
+
 /* ----------------------------------------------------------- output stage -- */
 
 /* What the reference does with the finished image before it writes image.ppm

@@ -438,6 +438,104 @@ int ref_import_obj(const char* path, float t0, float t1, pt_scene_desc** out)
     return 0;
 }
 
+// The scene of the reference's animation program (src/07/pathtracer-frames.cpp:63-177: a box of six posed quads,
+// the front one a light, and 100 falling spheres with two-key poses), set up with the classes of the final step
+// and the reference's own generator, then buildBVH(t0, t1) + flatten.  The statements that draw random numbers
+// are the reference's (src/07/pathtracer-frames.cpp:71-76,153-171), compiled by the same compiler, so the scene
+// is the one that program renders.
+int ref_frames_scene(float t0, float t1, pt_scene_desc** out)
+{
+    Scene scene;
+    std::vector<vec3> quadPos = { vec3(-1.0f, -1.0f, 0.0f), vec3(+1.0f, -1.0f, 0.0f), vec3(+1.0f, +1.0f, 0.0f),
+                                  vec3(-1.0f, +1.0f, 0.0f) };
+    std::vector<vec3> quadNrm;
+    std::vector<vec2> quadTc;
+    std::vector<unsigned int> quadInd = { 0, 1, 2, 0, 2, 3 };
+    Texture* boxTex = scene.take(new TextureConstant(vec3(0.6f)));
+    Material* boxMat = scene.take(new MaterialLambertian(boxTex));
+    struct Side {
+        vec3 translation;
+        float angle;
+        vec3 axis;
+    };
+    const Side sides[5] = { { vec3(0.0f, 0.0f, -10.0f), 0.0f, vec3(0.0f, 1.0f, 0.0f) },
+                            { vec3(-10.0f, 0.0f, -5.0f), 90.0f, vec3(0.0f, 1.0f, 0.0f) },
+                            { vec3(+10.0f, 0.0f, -5.0f), -90.0f, vec3(0.0f, 1.0f, 0.0f) },
+                            { vec3(0.0f, 10.0f, -5.0f), 90.0f, vec3(1.0f, 0.0f, 0.0f) },
+                            { vec3(0.0f, -10.0f, -5.0f), -90.0f, vec3(1.0f, 0.0f, 0.0f) } };
+    for (int k = 0; k < 5; k++) {
+        Transformation T;
+        T.translate(sides[k].translation);
+        if (k > 0)
+            T.rotate(quat(radians(sides[k].angle), sides[k].axis));
+        T.scale(vec3(10.0f));
+        Animation* A = scene.take(new AnimationConstant(T));
+        scene.take(new Mesh(quadPos, quadNrm, quadTc, quadInd, boxMat, A));
+    }
+    Material* lightMat = scene.take(new MaterialLight(vec3(1.0f)));
+    Transformation frontT;
+    frontT.rotate(quat(radians(180.0f), vec3(0.0f, 1.0f, 0.0f)));
+    frontT.scale(vec3(10.0f));
+    Animation* frontA = scene.take(new AnimationConstant(frontT));
+    // (that program's step of the course has no light list; in the final step a mesh is made known as a light
+    // when it is taken, src/15/scene.hpp:55-61, which is what lets pathSample sample it)
+    scene.take(new Mesh(quadPos, quadNrm, quadTc, quadInd, lightMat, frontA), true);
+    MtPrng prng(42);
+    for (int i = 0; i < 100; i++) {
+        float matP = prng.in01();
+        Material* mat;
+        if (matP < 0.1) {
+            Texture* tex = scene.take(new TextureConstant(vec3(1.0f)));
+            mat = new MaterialMirror(tex);
+        } else if (matP < 0.2) {
+            mat = new MaterialGlass(vec3(0.0f), 1.5f);
+        } else {
+            float kDFactor = 0.2f + 0.6f * prng.in01();
+            float kSFactor = 1.0f - kDFactor;
+            Texture* texKd = scene.take(new TextureConstant(kDFactor * vec3(
+                            prng.in01() * prng.in01(),
+                            prng.in01() * prng.in01(),
+                            prng.in01() * prng.in01())));
+            Texture* texKs = scene.take(new TextureConstant(kSFactor * vec3(prng.in01())));
+            Texture* texS = scene.take(new TextureConstant(vec3(120.0f * prng.in01())));
+            mat = new MaterialPhong(texKd, texKs, texS);
+        }
+        scene.take(mat);
+        MtPrng sp(123 + i);
+        float x = -3.0f + 6.0f * sp.in01();
+        float z = -2.0f - 6.0f * sp.in01();
+        float y0 = 9.7f - 8.0f * sp.in01();
+        float y1 = -9.7f + 8.0f * sp.in01();
+        float sc = 0.1f + sp.in01() * 0.2f;
+        Transformation T0, T1;
+        T0.translate(vec3(x, y0, z));
+        T0.scale(vec3(sc));
+        T1.translate(vec3(x, y1, z));
+        T1.scale(vec3(sc));
+        Animation* anim = scene.take(new AnimationTwoKey(T0, T1, 10.0f));
+        scene.take(new SurfaceSphere(vec3(0.0f), 1.0f, mat, anim));
+    }
+    scene.buildBVH(t0, t1);
+    std::unique_ptr<OwnedDesc> od(new OwnedDesc);
+    std::string err;
+    ptamd::FlattenOptions opt;
+    opt.translateAnimation = [](const Animation* a, pt_animation& o) {
+        const AnimationTwoKey* k = dynamic_cast<const AnimationTwoKey*>(a);
+        if (!k)
+            return false;
+        o.type = PT_ANIM_TWOKEY;
+        o.duration = k->duration;
+        o.T0 = ptamd::toPod(k->T0);
+        o.T1 = ptamd::toPod(k->T1);
+        return true;
+    };
+    if (!ptamd::flattenScene(scene, od->data, err, opt))
+        return fail(err);
+    od->desc = od->data.desc();
+    *out = &od.release()->desc;
+    return 0;
+}
+
 void ref_free_desc(pt_scene_desc* d)
 {
     if (d)

@@ -46,6 +46,8 @@ def lib():
         L.pt_last_kernel_ms.argtypes = [C.c_void_p]
         L.pt_scene_profile.argtypes = [C.c_void_p, C.c_int]
         L.pt_scene_kernel_times.argtypes = [C.c_void_p, C.POINTER(abi.pt_kernel_time), C.c_int, C.POINTER(C.c_int)]
+        L.pt_scene_count_walk.argtypes = [C.c_void_p, C.c_int]
+        L.pt_scene_walk_counters.argtypes = [C.c_void_p, C.POINTER(abi.pt_walk_counters)]
         L.pt_image_to_8bit.argtypes = [C.c_int, _fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
         L.pt_image_to_8bit_device.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                               C.c_void_p, C.c_void_p]
@@ -235,6 +237,33 @@ class FlatScene:
         self.nodes = np.zeros(0, NODE_DTYPE)
         self.depth = 0
         self._keep = []
+
+    @classmethod
+    def from_desc(cls, d):
+        """A copy of the arrays behind a pt_scene_desc (e.g. a scene file loaded by the library), open to changes."""
+        def arr(ptr, n, dtype, width=None):
+            if n == 0:
+                return np.zeros((0, width) if width else 0, dtype)
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dtype).itemsize * (width or 1),))
+            a = a.view(dtype).copy()
+            return a.reshape(-1, width) if width else a
+
+        s = cls()
+        nv = int(d.n_vertices)
+        s.positions, s.normals = arr(d.positions, nv, np.float32, 3), arr(d.normals, nv, np.float32, 3)
+        s.texcoords, s.tangents = arr(d.texcoords, nv, np.float32, 2), arr(d.tangents, nv, np.float32, 3)
+        s.indices = arr(d.indices, int(d.n_indices), np.uint32)
+        s.surfaces = arr(d.surfaces, int(d.n_surfaces), np.uint32, 4)
+        s.lights = [int(v) for v in arr(d.lights, int(d.n_lights), np.uint32)]
+        s.texels = arr(d.texels, int(d.n_texels), np.float32)
+        s.nodes = arr(d.bvh_nodes, int(d.n_bvh_nodes), NODE_DTYPE)
+        for name, ctype, n in (("meshes", abi.pt_mesh, d.n_meshes), ("spheres", abi.pt_sphere, d.n_spheres),
+                               ("materials", abi.pt_material, d.n_materials), ("textures", abi.pt_texture, d.n_textures),
+                               ("animations", abi.pt_animation, d.n_animations)):
+            src = getattr(d, name)
+            setattr(s, name, [ctype.from_buffer_copy(src[i]) for i in range(int(n))])
+        s.envmap = abi.pt_envmap.from_buffer_copy(d.envmap)
+        return s
 
     # -- animations / textures / materials
     def add_animation(self, anim):
@@ -590,10 +619,20 @@ class DeviceScene:
 
     def kernel_times(self):
         """{kernel name: (launches, total milliseconds)} since profile(True)."""
-        recs = (abi.pt_kernel_time * 8)()
+        recs = (abi.pt_kernel_time * 16)()
         n = C.c_int(0)
-        _check(lib().pt_scene_kernel_times(self.handle, recs, 8, C.byref(n)))
-        return {recs[i].name.decode(): (int(recs[i].launches), float(recs[i].total_ms)) for i in range(min(n.value, 8))}
+        _check(lib().pt_scene_kernel_times(self.handle, recs, 16, C.byref(n)))
+        return {recs[i].name.decode(): (int(recs[i].launches), float(recs[i].total_ms)) for i in range(min(n.value, 16))}
+
+    def count_walk(self, enable=True):
+        """Switch the instrumented tracing kernels on (clearing their sums) or off."""
+        _check(lib().pt_scene_count_walk(self.handle, 1 if enable else 0))
+
+    def walk_counters(self):
+        """Work of the executed walk since count_walk(True), as a dict (see pt_walk_counters)."""
+        c = abi.pt_walk_counters()
+        _check(lib().pt_scene_walk_counters(self.handle, C.byref(c)))
+        return c.as_dict()
 
     def render_samples(self, cam, params):
         out = np.empty((n_samples(params), 3), np.float32)

@@ -788,7 +788,8 @@ int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, in
     HIP_TRY(hipDeviceSynchronize());
     scene->kt.collect();
     static const char* const names[KernelTimes::kKinds] = { "generateKernel", "traceKernel", "shadeHitsKernel",
-                                                            "resolveKernel", "classifyKernel" };
+                                                            "resolveKernel", "classifyKernel", "traceOrderedKernel",
+                                                            "traceRetryKernel" };
     *count = KernelTimes::kKinds;
     for (int k = 0; k < KernelTimes::kKinds && k < capacity; k++) {
         std::memset(&out[k], 0, sizeof(out[k]));
@@ -797,6 +798,26 @@ int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, in
         out[k].total_ms = scene->kt.ms[k];
     }
     return PT_OK;
+}
+
+int pt_scene_count_walk(pt_scene* scene, int enable)
+{
+    if (!scene)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_count_walk: null scene");
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
+    HIP_TRY(hipDeviceSynchronize());
+    return ptWavefrontWalkStats(scene, enable);
+}
+
+int pt_scene_walk_counters(pt_scene* scene, pt_walk_counters* out)
+{
+    if (!scene || !out)
+        return fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_walk_counters: null argument");
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
+    HIP_TRY(hipDeviceSynchronize());
+    return ptWavefrontReadWalkStats(scene, out);
 }
 
 // ---------------------------------------------------------------- output stage

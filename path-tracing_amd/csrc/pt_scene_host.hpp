@@ -69,6 +69,7 @@ struct WavefrontBuffers {
     uint64_t accumCapacity = 0; // in pixels
     uint32_t* counters = nullptr;
     uint32_t* hostCounters = nullptr; // pinned
+    unsigned long long* walkStats = nullptr; // sums of the instrumented tracing kernels (see pt_walk_counters)
     bool fixed = false;      // the areas are parts of a fixed work area: never grown, never freed
     uint32_t fixedSlots = 0; // records per pool that the fixed pool area holds
 };
@@ -77,13 +78,13 @@ struct WavefrontBuffers {
 // stream a kernel is launched on.  begin(k) / end() bracket one launch; collect() (once the
 // streams have been synchronised) adds the elapsed times to the sums.
 struct KernelTimes {
-    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kKinds };
+    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kTraceOrdered, kTraceRetry, kKinds };
     bool enabled = false;
     std::vector<hipEvent_t> events; // pairs: start, stop
     std::vector<int> kinds;         // kind of pair i
     size_t used = 0;                // events in use
-    double ms[kKinds] = {0, 0, 0, 0, 0};
-    uint64_t launches[kKinds] = {0, 0, 0, 0, 0};
+    double ms[kKinds] = {};
+    uint64_t launches[kKinds] = {};
 
     void reset()
     {
@@ -151,6 +152,7 @@ struct pt_scene {
     uint64_t n_surfaces = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
+    bool walkStatsOn = false; // launch the instrumented tracing kernels (pt_scene_count_walk)
     bool hasDynamic = false; // some surface or sphere has a time-dependent (two-key) pose
     WavefrontBuffers wf;
     KernelTimes kt;
@@ -193,5 +195,7 @@ int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, co
                          pt_hit* d_out, hipStream_t stream);
 void ptWavefrontRelease(pt_scene* scene);
 // the work area in the library's image on `device` (which must be current): looked up once per device
+int ptWavefrontWalkStats(pt_scene* scene, int enable);
+int ptWavefrontReadWalkStats(pt_scene* scene, pt_walk_counters* out);
 int ptWavefrontStaticSetup(int device);
 int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);

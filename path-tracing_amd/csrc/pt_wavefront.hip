@@ -220,10 +220,42 @@ constexpr uint32_t kRefillLanesOrdered = PT_REFILL_LANES_ORDERED; // the same fo
 constexpr uint32_t kWalkLanesOrdered = PT_WALK_LANES_ORDERED;
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
-template <bool DYN, bool LDS>
-__global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
-                                                   float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
+// Work of the walk a tracing kernel actually executes, summed per launch when STATS is on (an instrumented
+// build of the kernel, chosen at launch; the plain one carries none of this).  Index into the scene's block of
+// 64-bit sums:
+enum : uint32_t {
+    kStatPathRays = 0, // rays of paths traced by the first pass
+    kStatShadowRays,   // queued shadow rays traced by the first pass
+    kStatBoxRows,      // 32-byte rows fetched for box tests: one node (storage-order walk) or the two children of an
+                       // inner node (nearer-child-first walk)
+    kStatLeafRows,     // nearer-child-first walk: exact leaf boxes read from the node table (32 bytes)
+    kStatSurfaceTests, // triangle / sphere tests (48-byte surface rows)
+    kStatRetryRays,    // rays handed to the storage-order second pass
+    kStatRetryNodes,   //   its node visits (32 bytes each)
+    kStatRetrySurfaceTests,
+    kStatWords
+};
+
+template <bool STATS>
+PT_DEV void addStats(unsigned long long* __restrict__ stats, uint32_t which, uint32_t mine)
 {
+    if (!STATS)
+        return;
+    // sum over the wave, one atomic per wave and counter
+    uint32_t v = mine;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    if (laneId() == 0 && v)
+        atomicAdd(&stats[which], (unsigned long long)v);
+}
+
+template <bool DYN, bool LDS, bool STATS>
+__global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
+                                                   float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
+                                                   unsigned long long* __restrict__ stats)
+{
+    uint32_t nRays = 0, nRows = 0, nTests = 0;
     // the queues this iteration's shadeKernel fills were read by the previous launch of this
     // kernel; this launch reads the other set
     if (blockIdx.x == 0)
@@ -321,6 +353,8 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
                     cur = 0;
                     pending = kInner;
                     best = noHit();
+                    if (STATS)
+                        nRays++;
                 }
             }
             pos = min(pos + nIdle, endPos);
@@ -330,12 +364,18 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
         {
             bool walking = have && pending == kInner && cur < sc.n_nodes;
             while (__builtin_amdgcn_ballot_w64(walking) != 0) {
-                if (walking)
+                if (walking) {
                     nodeStep<!LDS>(nodes, ray, 0.0001f, amax, cur, pending);
+                    if (STATS)
+                        nRows++;
+                }
                 walking = have && pending == kInner && cur < sc.n_nodes;
                 // (two steps per vote: the votes and branches cost more than the lanes idling in the second)
-                if (walking)
+                if (walking) {
                     nodeStep<!LDS>(nodes, ray, 0.0001f, amax, cur, pending);
+                    if (STATS)
+                        nRows++;
+                }
                 walking = have && pending == kInner && cur < sc.n_nodes;
                 if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
                     break;
@@ -345,6 +385,8 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
             if (surfaceTest<DYN>(sc, surf, pending, ray, 0.0001f, amax, best))
                 amax = best.a;
             pending = kInner;
+            if (STATS)
+                nTests++;
         }
         if (have && cur >= sc.n_nodes) {
             have = false;
@@ -357,6 +399,9 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
             }
         }
     }
+    addStats<STATS>(stats, shadow ? kStatShadowRays : kStatPathRays, nRays);
+    addStats<STATS>(stats, kStatBoxRows, nRows);
+    addStats<STATS>(stats, kStatSurfaceTests, nTests);
 }
 
 // The same job for scenes whose tree lives in memory, visiting the nearer child first.
@@ -417,10 +462,12 @@ PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx,
 #ifndef PT_ORDERED_WAVES
 #define PT_ORDERED_WAVES 6
 #endif
-template <bool DYN>
+template <bool DYN, bool STATS>
 __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
-                                                          float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves)
+                                                          float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
+                                                          unsigned long long* __restrict__ stats)
 {
+    uint32_t nRays = 0, nRows = 0, nLeafRows = 0, nTests = 0, nAmbiguous = 0;
     __shared__ uint2 stack[kStackDepth][256];
     __shared__ uint2 retryBuf[4][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
     uint32_t nRetry = 0;                     // entries in this wave's part (the same in every lane)
@@ -491,6 +538,10 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                     have = true;
                 }
                 if (have) {
+                    if (STATS) {
+                        nRays++;
+                        nRows++; // the root's box
+                    }
                     best = noHit();
                     cull = kFltMax;
                     otherT = kFltMax;
@@ -517,6 +568,8 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                 if (walking) {
                     const uint32_t k = link & ~kInnerBit;
                     const uint4 q0 = wide[2 * k + 0], q1 = wide[2 * k + 1];
+                    if (STATS)
+                        nRows++;
                     const V3 base = v3(sc.qbase[0], sc.qbase[1], sc.qbase[2]), step = v3(sc.qstep[0], sc.qstep[1], sc.qstep[2]);
                     const V3 lo1 = v3(fmaf(float(q0.x & 0xFFFFu), step.x, base.x), fmaf(float(q0.x >> 16), step.y, base.y),
                                       fmaf(float(q0.y & 0xFFFFu), step.z, base.z));
@@ -575,9 +628,13 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                 const uint32_t k = link & ~kLeafRowBit;
                 const float4 n0 = nodes[2 * k + 0], n1 = nodes[2 * k + 1];
                 float e;
+                if (STATS)
+                    nLeafRows++;
                 if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, e)) {
                     gate = e;
                     found = surfaceTest<DYN>(sc, surf, fbits(n1.w), ray, 0.0001f, cull, h);
+                    if (STATS)
+                        nTests++;
                 }
             } else {
                 // a static triangle: its box is that of its vertices (reference src/15/surface_triangle.hpp:44-45)
@@ -586,6 +643,8 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                 const V3 lo = v3(fminf(A.x, fminf(B.x, C.x)), fminf(A.y, fminf(B.y, C.y)), fminf(A.z, fminf(B.z, C.z)));
                 const V3 hi = v3(fmaxf(A.x, fmaxf(B.x, C.x)), fmaxf(A.y, fmaxf(B.y, C.y)), fmaxf(A.z, fmaxf(B.z, C.z)));
                 float e;
+                if (STATS)
+                    nTests++; // (the surface row is fetched whether or not its box is hit)
                 if (aabbEntry(lo, hi, ray, 0.0001f, cull, e)) {
                     gate = e;
                     float a, u, v;
@@ -645,6 +704,8 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                         = make_uint2(shadow ? (kRetryIsShadow | (itemBase + item)) : item, fbits(bound));
                 }
                 nRetry += uint32_t(__popcll(am));
+                if (STATS && ambiguous)
+                    nAmbiguous++;
             }
         }
         if (through) {
@@ -675,6 +736,11 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
         }
     }
     flushRetries(pool, counters, waveIdx, retryBuf[threadIdx.x >> 6], nRetry);
+    addStats<STATS>(stats, shadow ? kStatShadowRays : kStatPathRays, nRays);
+    addStats<STATS>(stats, kStatBoxRows, nRows);
+    addStats<STATS>(stats, kStatLeafRows, nLeafRows);
+    addStats<STATS>(stats, kStatSurfaceTests, nTests);
+    addStats<STATS>(stats, kStatRetryRays, nAmbiguous);
 }
 
 // The rays traceOrderedKernel left over, each traced to completion in storage order (reference
@@ -682,10 +748,11 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
 // boxes entered beyond it hold nothing that could be accepted after the surfaces within it, so
 // the walk sees the same surfaces win as one that starts unbounded.  They are few (a percent
 // of the rays or less), so the list fits the chip many times over.
-template <bool DYN>
+template <bool DYN, bool STATS>
 __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, const uint32_t* __restrict__ counters,
-                                                        float* __restrict__ samples)
+                                                        float* __restrict__ samples, unsigned long long* __restrict__ stats)
 {
+    Counters cnt = { 0, 0, 0, 0, 0, 0 };
     // block b works on sub-list b % kRetryShards (the grid is a multiple of kRetryShards blocks)
     const uint32_t list = blockIdx.x % kRetryShards;
     const uint32_t n = counters[(kCtrRetry + list) * kCtrStride];
@@ -696,7 +763,7 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
         if (!(e & kRetryIsShadow)) {
             const float4 o_t = pool.o_t[e], d_s = pool.d_s[e];
             const Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
-            const HitLite best = closestHit<false, DYN>(sc, ray, 0.0001f, bound, nullptr);
+            const HitLite best = closestHit<STATS, DYN>(sc, ray, 0.0001f, bound, &cnt);
             pool.hit[e] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                      fbits(best.a), fbits(best.u), fbits(best.v));
             pool.cls[e] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
@@ -715,10 +782,12 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
                 destW = fbits(r.w);
             }
             const Ray ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
-            const HitLite best = closestHit<false, DYN>(sc, ray, 0.0001f, bound, nullptr);
+            const HitLite best = closestHit<STATS, DYN>(sc, ray, 0.0001f, bound, &cnt);
             shadowArrive<DYN>(sc, sc.surf, pool, samples, q, ray, best, payload, dest, destW, destValue);
         }
     }
+    addStats<STATS>(stats, kStatRetryNodes, cnt.nodeVisits);
+    addStats<STATS>(stats, kStatRetrySurfaceTests, cnt.leafTests);
 }
 
 #ifndef PT_SHADE_WAVES
@@ -1242,6 +1311,10 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.counters), kCtrWords * sizeof(uint32_t)));
     if (!w.hostCounters)
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.hostCounters), kCtrWords * sizeof(uint32_t)));
+    if (!w.walkStats) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.walkStats), kStatWords * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(w.walkStats, 0, kStatWords * sizeof(unsigned long long)));
+    }
     return PT_OK;
 }
 
@@ -1255,7 +1328,7 @@ bool sceneFitsLds(const pt_scene* sc)
 }
 
 // the tracing step of one iteration
-template <bool DYN, bool LDS>
+template <bool DYN, bool LDS, bool STATS>
 void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_t stream, int parity)
 {
     const dim3 block(256);
@@ -1269,32 +1342,42 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
     const bool referenceOrder = traversal && std::strcmp(traversal, "reference") == 0;
     // (for scenes held in LDS the storage-order walk is the faster one: measured 353 against 610 us per launch)
     const bool ordered = !LDS && !referenceOrder && sc->dev.wide != nullptr;
-    sc->kt.begin(KernelTimes::kTrace, stream);
+    unsigned long long* stats = STATS ? w.walkStats : nullptr;
     if (ordered) {
-        hipLaunchKernelGGL((traceOrderedKernel<DYN>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity,
-                           w.samples, shadowCap, slotWaves);
+        sc->kt.begin(KernelTimes::kTraceOrdered, stream);
+        hipLaunchKernelGGL((traceOrderedKernel<DYN, STATS>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity,
+                           w.samples, shadowCap, slotWaves, stats);
+        sc->kt.end(stream);
         // a multiple of kRetryShards blocks: a few per sub-list, more only for large pools
         const uint32_t perList = std::min<uint32_t>(32u, std::max<uint32_t>(1u, pool.retryCap / 1024u));
         const uint32_t retryBlocks = kRetryShards * perList;
-        hipLaunchKernelGGL((traceRetryKernel<DYN>), dim3(retryBlocks), block, 0, stream, sc->dev, pool, w.counters,
-                           w.samples);
+        sc->kt.begin(KernelTimes::kTraceRetry, stream);
+        hipLaunchKernelGGL((traceRetryKernel<DYN, STATS>), dim3(retryBlocks), block, 0, stream, sc->dev, pool, w.counters,
+                           w.samples, stats);
+        sc->kt.end(stream);
     } else {
-        hipLaunchKernelGGL((traceKernel<DYN, LDS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
-                           w.samples, shadowCap, slotWaves);
+        sc->kt.begin(KernelTimes::kTrace, stream);
+        hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
+                           w.samples, shadowCap, slotWaves, stats);
+        sc->kt.end(stream);
     }
-    sc->kt.end(stream);
 }
 
 void launchTraceFor(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_t stream, int parity, bool dyn, bool lds)
 {
-    if (dyn && lds)
-        launchTrace<true, true>(sc, w, pool, stream, parity);
-    else if (dyn)
-        launchTrace<true, false>(sc, w, pool, stream, parity);
-    else if (lds)
-        launchTrace<false, true>(sc, w, pool, stream, parity);
-    else
-        launchTrace<false, false>(sc, w, pool, stream, parity);
+    // (the instrumented kernels only when the scene's walk statistics are switched on and their block exists)
+    const bool stats = sc->walkStatsOn && w.walkStats != nullptr;
+    const int which = (dyn ? 4 : 0) | (lds ? 2 : 0) | (stats ? 1 : 0);
+    switch (which) {
+    case 0: launchTrace<false, false, false>(sc, w, pool, stream, parity); break;
+    case 1: launchTrace<false, false, true>(sc, w, pool, stream, parity); break;
+    case 2: launchTrace<false, true, false>(sc, w, pool, stream, parity); break;
+    case 3: launchTrace<false, true, true>(sc, w, pool, stream, parity); break;
+    case 4: launchTrace<true, false, false>(sc, w, pool, stream, parity); break;
+    case 5: launchTrace<true, false, true>(sc, w, pool, stream, parity); break;
+    case 6: launchTrace<true, true, false>(sc, w, pool, stream, parity); break;
+    default: launchTrace<true, true, true>(sc, w, pool, stream, parity); break;
+    }
 }
 
 // Run one batch of samples [b.sFirst, b.sFirst + b.nS) of every pixel of the tile into the sample buffer.
@@ -1568,6 +1651,28 @@ int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, 
     return rc;
 }
 
+// Switch the instrumented tracing kernels on (clearing the sums) or off; read the sums.
+int ptWavefrontWalkStats(pt_scene* scene, int enable)
+{
+    WavefrontBuffers& w = scene->wf;
+    if (enable) {
+        if (!w.walkStats)
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.walkStats), kStatWords * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(w.walkStats, 0, kStatWords * sizeof(unsigned long long)));
+    }
+    scene->walkStatsOn = enable != 0;
+    return PT_OK;
+}
+
+int ptWavefrontReadWalkStats(pt_scene* scene, pt_walk_counters* out)
+{
+    static_assert(sizeof(pt_walk_counters) == kStatWords * sizeof(unsigned long long), "one field per sum");
+    std::memset(out, 0, sizeof(*out));
+    if (scene->wf.walkStats)
+        HIP_TRY(hipMemcpy(out, scene->wf.walkStats, sizeof(*out), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 void ptWavefrontRelease(pt_scene* scene)
 {
     WavefrontBuffers& w = scene->wf;
@@ -1581,6 +1686,8 @@ void ptWavefrontRelease(pt_scene* scene)
         (void)hipFree(w.counters);
     if (w.hostCounters)
         (void)hipHostFree(w.hostCounters);
+    if (w.walkStats)
+        (void)hipFree(w.walkStats);
     w = WavefrontBuffers();
     scene->kt.release();
 }

@@ -16,7 +16,8 @@ combined by ONE sum-reduce to rank 0 (RCCL over xGMI on GPUs, gloo in CPU tests)
   batches   every rank renders the same pixels and a full set of samples with its own seed, the way
             independent renders are averaged; rank 0 divides by spp * world.  This is the weak-scaling
             mode of bench.py.
-  frames    whole frames per rank, no combine (plan_frames).
+  frames    whole frames per rank, no combine (plan_frames); plan_frames_and_samples also splits the frames
+            left over by sample range.
 
 Nothing here renders: the caller passes a `render(params, out)` callable (the GPU library in
 production, the CPU oracle in the gloo tests).
@@ -46,6 +47,19 @@ def plan_samples(n_samples, world, rank):
 def plan_frames(n_frames, world, rank):
     """Frames of this rank, round robin (frame f goes to rank f % world)."""
     return list(range(rank, n_frames, world))
+
+
+def plan_frames_and_samples(n_frames, n_samples, world, rank):
+    """This rank's work for an animation of n_frames: (frame, None) for a whole frame of its own, or
+    (frame, (begin, end)) for its sample range of a frame that all ranks render together.  Whole frames go round
+    robin for as long as every rank gets one; the n_frames % world frames left over are split by samples, so that
+    no rank idles through the last round (the reference shards by frame only, src/07/pathtracer-frames.cpp:205-207)."""
+    full = n_frames - n_frames % world
+    plan = [(f, None) for f in range(rank, full, world)]
+    if world > 1:
+        for f in range(full, n_frames):
+            plan.append((f, plan_samples(n_samples, world, rank)))
+    return plan
 
 
 def shard_params(base, mode, world, rank, tile=32):

@@ -50,6 +50,12 @@ class Reference:
         self._check(self.lib.ref_import_obj(path.encode(), C.c_float(t0), C.c_float(t1), C.byref(out)))
         return out
 
+    def frames_scene(self, t0=0.0, t1=0.0):
+        """The scene of the reference's animation program (src/07/pathtracer-frames.cpp:63-177), flattened."""
+        out = C.POINTER(abi.pt_scene_desc)()
+        self._check(self.lib.ref_frames_scene(C.c_float(t0), C.c_float(t1), C.byref(out)))
+        return out
+
     def free_desc(self, desc_ptr):
         self.lib.ref_free_desc(desc_ptr)
 

@@ -16,27 +16,7 @@ from path_tracing_amd import abi
 FAMILIES = ["materials", "spheres", "animated", "noise", "envonly", "meshlight"]
 
 
-def quat(angle_deg, axis):
-    a = np.asarray(axis, np.float64)
-    a = a / np.linalg.norm(a)
-    h = math.radians(angle_deg) * 0.5
-    s = math.sin(h)
-    return (float(np.float32(a[0] * s)), float(np.float32(a[1] * s)), float(np.float32(a[2] * s)),
-            float(np.float32(math.cos(h))))
-
-
-def lookat_animation(eye, center):
-    """Constant camera pose looking from eye to center (any unit quaternion is a valid input)."""
-    f = np.asarray(center, np.float64) - np.asarray(eye, np.float64)
-    f /= np.linalg.norm(f)
-    z = np.array([0.0, 0.0, -1.0])
-    axis = np.cross(z, f)
-    if np.linalg.norm(axis) < 1e-9:
-        q = (0.0, 0.0, 0.0, 1.0)
-    else:
-        ang = math.degrees(math.acos(max(-1.0, min(1.0, float(np.dot(z, f))))))
-        q = quat(ang, axis)
-    return pt.make_animation(abi.PT_ANIM_CONSTANT, pt.make_transform(eye, q, (1, 1, 1)))
+from path_tracing_amd.workloads import big_mesh_scene, displaced_grid, lookat_animation, quat  # noqa: E402,F401
 
 
 QUAD_POS = np.array([[-1, -1, 0], [1, -1, 0], [-1, 1, 0], [1, 1, 0]], np.float32)
@@ -248,19 +228,6 @@ def family_envonly():
     return s, cam, pt.make_params(32, 24, 3, seed=3)
 
 
-def displaced_grid(n, seed=1, extent=100.0, amplitude=0.02):
-    """(n x n x 2) triangles over [-extent, extent]^2 in xz, heights displaced by seeded noise."""
-    rng = np.random.default_rng(seed)
-    xs = np.linspace(-extent, extent, n + 1, dtype=np.float32)
-    X, Z = np.meshgrid(xs, xs, indexing="xy")
-    Y = (rng.standard_normal((n + 1, n + 1)) * extent * amplitude).astype(np.float32)
-    pos = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
-    i = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).ravel()
-    a, b, c, e = i, i + 1, i + n + 1, i + n + 2
-    idx = np.stack([a, c, b, b, c, e], -1).reshape(-1).astype(np.uint32)
-    return pos, idx
-
-
 def family_meshlight():
     """A displaced-grid mesh under an emissive mesh with several light triangles."""
     s = pt.FlatScene()
@@ -289,21 +256,6 @@ _BUILDERS = {
 
 def build(name, _ref=None):
     return _BUILDERS[name]()
-
-
-def big_mesh_scene(n, seed=1):
-    """Displaced grid of 2 n^2 triangles at extent +-100 with an emissive quad overhead
-    (the 'multi-million-triangle' shape of the benchmark; n = 1000 gives 2 M triangles)."""
-    s = pt.FlatScene()
-    pos, idx = displaced_grid(n, seed=seed, extent=100.0, amplitude=0.01)
-    s.add_mesh(pos, idx, s.material_lambertian(s.texture_constant((0.7, 0.6, 0.5))))
-    quad = np.array([[-30, 60, -30], [30, 60, -30], [30, 60, 30], [-30, 60, 30]], np.float32)
-    s.add_mesh(quad, np.array([0, 1, 2, 0, 2, 3], np.uint32), s.material_light((10.0, 10.0, 10.0)), is_light=True)
-    s.set_envmap_equirect(s.texture_constant((0.4, 0.5, 0.7)))
-    s.build_bvh()
-    cam = pt.make_camera(math.tan(math.radians(25.0)), math.tan(math.radians(25.0)) * 16 / 9, 1.0, 0.0,
-                         lookat_animation((0.0, 45.0, 140.0), (0.0, 0.0, 0.0)))
-    return s, cam
 
 
 def output_stage_image():

@@ -1,0 +1,88 @@
+"""The file-based benchmark workloads on the GPU, against the oracle bit for bit and against the vectors the
+reference computed for them: the textured multi-material OBJ scene (image textures, opacity, bump and normal maps;
+tables in memory), and the scene of the reference's animation program with the tree replaced per frame, built on
+the host and on the device."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import path_tracing_amd as pt
+from path_tracing_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+OUTLIER_FRACTION = 1e-3
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def rel_outliers(a, ref):
+    scale = np.maximum(np.abs(ref).max(axis=-1), 1e-3)
+    err = np.abs(a - ref).max(axis=-1) / scale
+    return float(np.mean(~(err <= REL_TOL)))
+
+
+def test_textured_scene(golden_dir, oracle):
+    scene = pt.LoadedScene(os.path.join(golden_dir, "textured.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "textured.ptcam"))
+    ph = pt.make_params(96, 54, 1)
+    p = pt.make_params(48, 27, 2, seed=7, max_path_segments=32)
+    with pt.DeviceScene(scene) as dev:
+        hits = dev.primary_hits(cam, ph)
+        smp = dev.render_samples(cam, p)
+        img = dev.render(cam, pt.make_params(64, 36, 2, seed=3, samples=(1, 4), max_path_segments=32))
+        os.environ["PT_TRAVERSAL"] = "reference"
+        try:
+            smp_ref_order = dev.render_samples(cam, p)
+        finally:
+            del os.environ["PT_TRAVERSAL"]
+    golden_hits = np.load(os.path.join(golden_dir, "textured_hits_96x54.npy"))
+    assert hits.tobytes() == oracle.primary_hits(scene.ptr, cam, ph, math_mode=1).tobytes()
+    for field in ("surface", "material", "backside"):
+        assert np.array_equal(hits[field], golden_hits[field])
+    np.testing.assert_allclose(hits["a"], golden_hits["a"], rtol=1e-5)
+    assert same_bits(smp, oracle.render_samples(scene.ptr, cam, p, math_mode=1))
+    assert same_bits(smp, smp_ref_order)
+    assert rel_outliers(smp, np.load(os.path.join(golden_dir, "textured_samples_48x27x4.npy"))) <= OUTLIER_FRACTION
+    want = oracle.render(scene.ptr, cam, pt.make_params(64, 36, 2, seed=3, samples=(1, 4), max_path_segments=32), math_mode=1)
+    assert same_bits(img, want)
+
+
+@pytest.mark.parametrize("frame", [0, 100, 239])
+def test_frames_scene(frame, golden_dir, oracle):
+    loaded = pt.LoadedScene(os.path.join(golden_dir, "frames.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "frames.ptcam"))
+    s = pt.FlatScene.from_desc(loaded.desc())
+    t0, t1 = workloads.frame_interval(frame)
+    ph = pt.make_params(96, 54, 1, seed=42 + frame, t0=t0, t1=t1)
+    p = pt.make_params(48, 27, 2, seed=42 + frame, t0=t0, t1=t1)
+    golden_hits = np.load(os.path.join(golden_dir, "frames_f%d_hits_96x54.npy" % frame))
+    golden = np.load(os.path.join(golden_dir, "frames_f%d_samples_48x27x4.npy" % frame))
+    with pt.DeviceScene(loaded) as dev:
+        # the reference's tree for this frame
+        dev.update_bvh(s.build_bvh(t0, t1))
+        d = s.desc()
+        hits = dev.primary_hits(cam, ph)
+        smp = dev.render_samples(cam, p)
+        assert hits.tobytes() == oracle.primary_hits(C.byref(d), cam, ph, math_mode=1).tobytes()
+        for field in ("surface", "material", "backside"):
+            assert np.array_equal(hits[field], golden_hits[field])
+        assert same_bits(smp, oracle.render_samples(C.byref(d), cam, p, math_mode=1))
+        assert rel_outliers(smp, golden) <= OUTLIER_FRACTION
+        # the tree built on the device over the same interval: the oracle on that tree, bit for bit; against the
+        # reference's tree the same surfaces except exact ties
+        dev.build_bvh_device(t0, t1)
+        s.nodes = dev.get_bvh()
+        d2 = s.desc()
+        smp_dev = dev.render_samples(cam, p)
+        assert same_bits(smp_dev, oracle.render_samples(C.byref(d2), cam, p, math_mode=1))
+        hits_dev = dev.primary_hits(cam, ph)
+        assert np.mean(hits_dev["surface"] != golden_hits["surface"]) <= 5e-3
+        assert rel_outliers(smp_dev, golden) <= 0.02
