@@ -308,6 +308,28 @@ int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_p
 int pt_render_device_noalloc(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                              float* d_out_rgb, void* hip_stream);
 
+/* One image rendered by several GPUs of a node.  The reference shards by
+ * process and file: tiles written as raw rows and stitched by a second program
+ * (reference src/07/pathtracer-tiles.cpp:72-139, tile-composer.cpp:10-37).
+ * Here the caller creates the scene once per GPU (pt_scene_create with
+ * different device numbers; two handles on one GPU are allowed) and
+ * pt_render_multi renders `params` with one host thread per handle:
+ *   PT_SHARD_TILES    256 x 256 tiles of the rectangle round robin over the
+ *                     handles, gathered by peer copies into the first handle's
+ *                     GPU: the image equals pt_render's bit for bit;
+ *   PT_SHARD_SAMPLES  contiguous ranges of the sample indices, partial sums
+ *                     added on the first handle's GPU in handle order: equals
+ *                     pt_render's image to rounding (another addition order).
+ * out_rgb as for pt_render.  pt_multi_plan gives the render calls of share
+ * `share` of `n_shares` (pure host code; call with capacity 0 for the count);
+ * a distributed caller (one process per GPU) renders its share's calls with
+ * pt_render_device and combines with a collective instead. */
+enum { PT_SHARD_TILES = 0, PT_SHARD_SAMPLES = 1 };
+int pt_multi_plan(const pt_render_params* params, int mode, int n_shares, int share, pt_render_params* out_calls,
+                  int capacity, int* out_count);
+int pt_render_multi(pt_scene* const* scenes, int n_scenes, const pt_camera* camera, const pt_render_params* params,
+                    int mode, float* out_rgb);
+
 /* Closest hits of n caller-supplied rays: BVHTreeLinear::hit(ray, amin, amax)
  * (reference src/15/bvh.hpp:183-213) for each.  Host arrays: origins and
  * directions 3 floats per ray, times 1 per ray (may be NULL = 0). */

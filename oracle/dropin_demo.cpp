@@ -41,6 +41,8 @@ int main(int argc, char* argv[])
     const int height = argc > 3 ? atoi(argv[3]) : 64;
     const int sqrtSpp = argc > 4 ? atoi(argv[4]) : 3;
     const bool deviceBvh = argc > 5 && std::string(argv[5]) == "devicebvh";
+    // `multi`: the image split by tiles over two scene handles (both on GPU 0 when the machine has one)
+    const bool multi = argc > 5 && std::string(argv[5]) == "multi";
 
     Scene scene;
     // a floor: one textured quad under a constant pose
@@ -74,7 +76,9 @@ int main(int argc, char* argv[])
 
     // was: the pixel loop of src/15/pathtracer.cpp:199-221
     std::string err;
-    std::vector<vec3> img = ptamd::render(scene, camera, width, height, sqrtSpp, 0.0f, 0.0f, &err, 42);
+    std::vector<vec3> img = multi
+        ? ptamd::renderMulti(scene, camera, width, height, sqrtSpp, 0.0f, 0.0f, { 0, pt_device_count() > 1 ? 1 : 0 }, &err, 42)
+        : ptamd::render(scene, camera, width, height, sqrtSpp, 0.0f, 0.0f, &err, 42);
     if (img.empty()) {
         fprintf(stderr, "render failed: %s\n", err.c_str());
         return 1;

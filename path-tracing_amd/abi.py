@@ -110,6 +110,9 @@ class pt_kernel_time(C.Structure):
     _fields_ = [("name", C.c_char * 24), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
 
+PT_SHARD_TILES, PT_SHARD_SAMPLES = 0, 1
+
+
 class pt_walk_counters(C.Structure):
     _fields_ = [("path_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("box_rows", C.c_uint64),
                 ("leaf_rows", C.c_uint64), ("surface_tests", C.c_uint64), ("retry_rays", C.c_uint64),

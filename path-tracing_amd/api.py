@@ -70,6 +70,10 @@ def lib():
                                        C.c_void_p, C.c_void_p]
         L.pt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params),
                                                C.c_void_p, C.c_void_p]
+        L.pt_multi_plan.argtypes = [C.POINTER(abi.pt_render_params), C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(abi.pt_render_params), C.c_int, C.POINTER(C.c_int)]
+        L.pt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(abi.pt_camera),
+                                      C.POINTER(abi.pt_render_params), C.c_int, _fp]
         L.pt_render_counted.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp,
                                         C.POINTER(abi.pt_counters)]
         L.pt_render_samples.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp]
@@ -544,6 +548,24 @@ def save_camera(cam, path):
 
 
 # ---------------------------------------------------------- device scenes --
+
+def multi_plan(params, mode, n_shares, share):
+    """The render calls (pt_render_params) of one share of an image split over n_shares GPUs (pt_multi_plan)."""
+    n = C.c_int(0)
+    _check(lib().pt_multi_plan(C.byref(params), mode, n_shares, share, None, 0, C.byref(n)))
+    calls = (abi.pt_render_params * max(n.value, 1))()
+    _check(lib().pt_multi_plan(C.byref(params), mode, n_shares, share, calls, n.value, C.byref(n)))
+    return [abi.pt_render_params.from_buffer_copy(calls[i]) for i in range(n.value)]
+
+
+def render_multi(device_scenes, cam, params, mode=abi.PT_SHARD_TILES, out=None):
+    """pt_render_multi over a list of DeviceScene handles (one per GPU): (height, width, 3) float32."""
+    if out is None:
+        out = np.zeros((params.height, params.width, 3), np.float32)
+    handles = (C.c_void_p * len(device_scenes))(*[d.handle for d in device_scenes])
+    _check(lib().pt_render_multi(handles, len(device_scenes), C.byref(cam), C.byref(params), mode, _f(out)))
+    return out
+
 
 class DeviceScene:
     """A scene resident in HBM on one GPU (pt_scene)."""

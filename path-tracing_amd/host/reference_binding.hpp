@@ -491,6 +491,58 @@ inline std::vector<vec3> render(const Scene& scene, const Camera& camera, int wi
     return img;
 }
 
+// The same over several GPUs of the node: the scene is uploaded to every device of `devices` and the image is
+// split by tiles (bit-identical to one GPU) -- what the reference does with one process per tile and a composer
+// program (src/07/pathtracer-tiles.cpp:72-139, tile-composer.cpp:10-37).
+inline std::vector<vec3> renderMulti(const Scene& scene, const Camera& camera, int width, int height, int sqrtSpp,
+                                     float t0, float t1, const std::vector<int>& devices, std::string* err = nullptr,
+                                     uint64_t seed = 42, int mode = PT_SHARD_TILES,
+                                     const FlattenOptions& opt = FlattenOptions())
+{
+    std::vector<vec3> img;
+    std::string e;
+    ptio::SceneData flat;
+    pt_camera cam;
+    if (devices.empty() || !flattenScene(scene, flat, e, opt) || !flattenCamera(camera, cam, e, opt)) {
+        if (err)
+            *err = devices.empty() ? "no devices given" : e;
+        return img;
+    }
+    pt_scene_desc desc = flat.desc();
+    std::vector<pt_scene*> handles;
+    bool ok = true;
+    for (int device : devices) {
+        pt_scene* dev = nullptr;
+        ok = pt_scene_create(&desc, device, &dev) == PT_OK;
+        if (ok)
+            handles.push_back(dev);
+        ok = ok && (desc.n_bvh_nodes != 0 || pt_scene_build_bvh_device(dev, t0, t1, nullptr) == PT_OK);
+        if (!ok)
+            break;
+    }
+    if (ok) {
+        pt_render_params params;
+        std::memset(&params, 0, sizeof(params));
+        params.width = width;
+        params.height = height;
+        params.sqrt_spp = sqrtSpp;
+        params.t0 = t0;
+        params.t1 = t1;
+        params.seed = seed;
+        img.resize(size_t(width) * height);
+        ok = pt_render_multi(handles.data(), int(handles.size()), &cam, &params, mode, reinterpret_cast<float*>(img.data()))
+            == PT_OK;
+    }
+    if (!ok) {
+        if (err)
+            *err = pt_last_error();
+        img.clear();
+    }
+    for (pt_scene* h : handles)
+        pt_scene_destroy(h);
+    return img;
+}
+
 // Drop-in for to8Bit(img) (reference src/15/color.hpp:84-98, used at src/15/pathtracer.cpp:225):
 // same bytes in the same (image) row order, computed on the GPU; saveImageAsPPM then writes
 // them as before.  Empty on failure.

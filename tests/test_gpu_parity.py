@@ -279,6 +279,39 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
     assert dev.walk_counters() == c
 
 
+def test_render_multi_with_two_handles_on_one_gpu(cornell, oracle):
+    """pt_render_multi rehearsed on one GPU: two scene handles (as if on two GPUs), one host thread each.  Tiles:
+    the single-handle image bit for bit (also with a rectangle and a sample range, leaving the other pixels
+    alone).  Samples: the sum of the handles' partial sums in handle order, then one division -- checked against
+    that very sequence on the oracle's partial images, bit for bit, and against the sequential image to rounding."""
+    scene, cam, dev = cornell
+    with pt.DeviceScene(scene) as dev2, pt.DeviceScene(scene) as dev3:
+        p = pt.make_params(600, 300, 3, seed=5)
+        single = dev.render(cam, p)
+        assert same_bits(pt.render_multi([dev, dev2], cam, p, pt.abi.PT_SHARD_TILES), single)
+        assert same_bits(pt.render_multi([dev, dev2, dev3], cam, p, pt.abi.PT_SHARD_TILES), single)
+        q = pt.make_params(600, 300, 3, seed=5, tile=(17, 40, 590, 299), samples=(2, 7))
+        out = np.full((300, 600, 3), -2.0, np.float32)
+        want = np.full((300, 600, 3), -2.0, np.float32)
+        dev.render(cam, q, out=want)
+        assert same_bits(pt.render_multi([dev, dev2], cam, q, pt.abi.PT_SHARD_TILES, out=out), want)
+        # sample ranges
+        small = pt.make_params(96, 64, 3, seed=6)
+        got = pt.render_multi([dev, dev2, dev3], cam, small, pt.abi.PT_SHARD_SAMPLES)
+        parts = [oracle.render(scene.ptr, cam, c, math_mode=1) for k in range(3)
+                 for c in pt.multi_plan(small, pt.abi.PT_SHARD_SAMPLES, 3, k)]
+        acc = parts[0]
+        for part in parts[1:]:
+            acc = acc + part
+        assert same_bits(got, acc / np.float32(9.0))
+        np.testing.assert_allclose(got, dev.render(cam, small), rtol=2e-6, atol=1e-7)
+        out = np.full((64, 96, 3), 5.0, np.float32)
+        r = pt.make_params(96, 64, 3, seed=6, tile=(8, 8, 90, 60), samples=(1, 8))
+        pt.render_multi([dev, dev2], cam, r, pt.abi.PT_SHARD_SAMPLES, out=out)
+        assert np.all(out[:8] == 5.0) and np.all(out[:, 90:] == 5.0)
+        np.testing.assert_allclose(out[8:60, 8:90], dev.render(cam, r)[8:60, 8:90], rtol=2e-6, atol=1e-7)
+
+
 def test_full_size_properties(oracle, golden_dir):
     """The benchmark's image size (1920x1080), through properties that need no full-size oracle render:
     primary hits against the oracle (2 M rays, seconds on the CPU), a tile of the full render bit for
@@ -436,6 +469,12 @@ def test_dropin_program(tmp_path, oracle):
     assert same_bits(img, want)
     assert np.array_equal(u8, oracle.image_to_8bit(img, flip_rows=False, math_mode=1))
     assert img.mean() > 0.01
+    # the same program rendering through ptamd::renderMulti (two scene handles, image split by tiles): the same bits
+    r = subprocess.run([exe, prefix + "_multi", "600", "300", str(s), "multi"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    img_multi = np.fromfile(prefix + "_multi.img", np.float32).reshape(300, 600, 3)
+    cam_multi = pt.load_camera(prefix + "_multi.ptcam")
+    assert same_bits(img_multi, oracle.render(scene.ptr, cam_multi, pt.make_params(600, 300, s, seed=42), math_mode=1))
     # the same program leaving the tree to the binding (built on the GPU): the same image except where a ray
     # meets two surfaces at exactly the same distance
     r = subprocess.run([exe, prefix + "_dev", str(w), str(h), str(s), "devicebvh"], capture_output=True, text=True,

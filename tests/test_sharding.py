@@ -32,6 +32,39 @@ def test_sample_and_frame_plans_partition():
         assert frames == list(range(240))
 
 
+def test_multi_plan_of_the_library_partitions_pixels_and_samples():
+    """pt_multi_plan (what pt_render_multi's threads render): tiles cover the rectangle once, sample ranges the
+    sample range once; it agrees with the Python planner used by the one-process-per-GPU path."""
+    base = pt.make_params(1000, 600, 5, tile=(30, 20, 990, 600), samples=(3, 22))
+    for world in (1, 2, 3, 8):
+        cover = np.zeros((600, 1000), np.int32)
+        for share in range(world):
+            for c in pt.multi_plan(base, pt.abi.PT_SHARD_TILES, world, share):
+                assert (c.sample_begin, c.sample_end, c.flags) == (3, 22, 0)
+                cover[c.tile_y0:c.tile_y1, c.tile_x0:c.tile_x1] += 1
+        assert np.all(cover[20:600, 30:990] == 1) and cover.sum() == 580 * 960
+        ranges = []
+        for share in range(world):
+            calls = pt.multi_plan(base, pt.abi.PT_SHARD_SAMPLES, world, share)
+            assert len(calls) == 1
+            c = calls[0]
+            assert (c.tile_x0, c.tile_y0, c.tile_x1, c.tile_y1) == (30, 20, 990, 600)
+            assert c.flags & pt.abi.PT_RENDER_SUM_ONLY
+            ranges.append((c.sample_begin, c.sample_end))
+        assert ranges[0][0] == 3 and ranges[-1][1] == 22
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    # more shares than samples: the extra shares have nothing to do
+    few = pt.make_params(64, 64, 1)
+    assert [len(pt.multi_plan(few, pt.abi.PT_SHARD_SAMPLES, 4, k)) for k in range(4)] == [1, 0, 0, 0]
+    full = pt.make_params(1000, 600, 5)
+    mine = [(c.sample_begin, c.sample_end) for k in range(3) for c in pt.multi_plan(full, pt.abi.PT_SHARD_SAMPLES, 3, k)]
+    assert mine == [shard.plan_samples(25, 3, k) for k in range(3)]
+    with pytest.raises(pt.PtError):
+        pt.multi_plan(full, 7, 2, 0)
+    with pytest.raises(pt.PtError):
+        pt.multi_plan(full, pt.abi.PT_SHARD_TILES, 2, 2)
+
+
 WORKER = r'''
 import ctypes as C, os, sys
 import numpy as np
