@@ -448,6 +448,26 @@ int pt_bump_to_normal_map(int device, const float* bump_texels, int width, int h
 int pt_bump_to_normal_map_device(int device, const float* d_bump_texels, int width, int height, float bump_factor,
                                  float* d_out_texels, void* hip_stream);
 
+/* The importer's vertex re-indexing for one (material, shape) pair, on the GPU:
+ * what the loop at reference src/15/import.hpp:240-284 computes through a
+ * std::map per pair.  In: the shape as the OBJ parser delivers it -- per face
+ * corner (3 per triangle, file order) the position / normal / texcoord index
+ * (-1 = none), per triangle its material id -- the file's attribute arrays, and
+ * the pair's material id.  Out: the index list of the faces with that material
+ * (a new vertex number per distinct index triple, numbered in order of first
+ * appearance) and the vertices in that numbering: positions, normals
+ * (normalised, import.hpp:265-267) and texcoords.  Normals (texcoords) are
+ * delivered only if every distinct triple has one (out_have_* = 0 otherwise:
+ * the importer then builds the Mesh without them, import.hpp:281-284).  The out
+ * arrays hold up to 3 * n_triangles indices / vertices.  Streams are identical
+ * to the importer's bit for bit. */
+int pt_mesh_reindex(int device, const int32_t* corner_vi, const int32_t* corner_ni, const int32_t* corner_ti,
+                    const int32_t* tri_material, uint64_t n_triangles, int32_t material, const float* vertices,
+                    uint64_t n_vertices, const float* normals, uint64_t n_normals, const float* texcoords,
+                    uint64_t n_texcoords, uint32_t* out_indices, float* out_positions, float* out_normals,
+                    float* out_texcoords, uint64_t* out_n_indices, uint64_t* out_n_vertices, int* out_have_normals,
+                    int* out_have_texcoords);
+
 /* ------------------------------------------------------- host-side helpers -- */
 
 /* Build the acceleration structure over [t0, t1] exactly as

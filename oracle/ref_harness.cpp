@@ -536,6 +536,65 @@ int ref_frames_scene(float t0, float t1, pt_scene_desc** out)
     return 0;
 }
 
+// What the importer's re-indexing loop (src/15/import.hpp:233-289) starts from: the file as tinyobj parses it with
+// the importer's settings (import.hpp:121-125).  sizes: vertices, normals, texcoords, shapes, materials, corners of
+// all shapes.  Arrays: attributes; per shape the first corner (n_shapes + 1 entries); per corner the three
+// indices; per triangle the material id.
+struct ref_obj {
+    tinyobj::ObjReader reader;
+};
+
+int ref_obj_parse(const char* path, ref_obj** out, uint64_t* sizes)
+{
+    std::unique_ptr<ref_obj> o(new ref_obj);
+    tinyobj::ObjReaderConfig conf;
+    conf.triangulate = true;
+    conf.vertex_color = false;
+    o->reader.ParseFromFile(path, conf);
+    if (!o->reader.Valid())
+        return fail("tinyobj cannot read the file");
+    const tinyobj::attrib_t& a = o->reader.GetAttrib();
+    uint64_t corners = 0;
+    for (const tinyobj::shape_t& sh : o->reader.GetShapes())
+        corners += sh.mesh.indices.size();
+    sizes[0] = a.vertices.size() / 3;
+    sizes[1] = a.normals.size() / 3;
+    sizes[2] = a.texcoords.size() / 2;
+    sizes[3] = o->reader.GetShapes().size();
+    sizes[4] = o->reader.GetMaterials().size();
+    sizes[5] = corners;
+    *out = o.release();
+    return 0;
+}
+
+int ref_obj_arrays(const ref_obj* o, float* vertices, float* normals, float* texcoords, uint64_t* shape_first_corner,
+                   int32_t* vi, int32_t* ni, int32_t* ti, int32_t* tri_material)
+{
+    const tinyobj::attrib_t& a = o->reader.GetAttrib();
+    std::memcpy(vertices, a.vertices.data(), a.vertices.size() * sizeof(float));
+    std::memcpy(normals, a.normals.data(), a.normals.size() * sizeof(float));
+    std::memcpy(texcoords, a.texcoords.data(), a.texcoords.size() * sizeof(float));
+    uint64_t c = 0;
+    size_t k = 0;
+    for (const tinyobj::shape_t& sh : o->reader.GetShapes()) {
+        shape_first_corner[k++] = c;
+        for (size_t i = 0; i < sh.mesh.indices.size(); i++, c++) {
+            vi[c] = sh.mesh.indices[i].vertex_index;
+            ni[c] = sh.mesh.indices[i].normal_index;
+            ti[c] = sh.mesh.indices[i].texcoord_index;
+            if (i % 3 == 0)
+                tri_material[c / 3] = sh.mesh.material_ids[i / 3];
+        }
+    }
+    shape_first_corner[k] = c;
+    return 0;
+}
+
+void ref_obj_free(ref_obj* o)
+{
+    delete o;
+}
+
 void ref_free_desc(pt_scene_desc* d)
 {
     if (d)

@@ -549,6 +549,34 @@ def save_camera(cam, path):
 
 # ---------------------------------------------------------- device scenes --
 
+def _reindex(fn, lead, vi, ni, ti, tri_material, material, vertices, normals, texcoords):
+    vi, ni, ti = (np.ascontiguousarray(a, np.int32) for a in (vi, ni, ti))
+    tri_material = np.ascontiguousarray(tri_material, np.int32)
+    vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    texcoords = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+    nt = len(tri_material)
+    idx = np.zeros(max(3 * nt, 1), np.uint32)
+    pos, nrm, tc = np.zeros((max(3 * nt, 1), 3), np.float32), np.zeros((max(3 * nt, 1), 3), np.float32), np.zeros((max(3 * nt, 1), 2), np.float32)
+    n_idx, n_v, hn, ht = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
+    ip = lambda a: a.ctypes.data_as(C.c_void_p)
+    sizes = lambda a: [C.c_uint64(len(a))] if lead else []
+    args = list(lead) + [ip(vi), ip(ni), ip(ti), ip(tri_material), C.c_uint64(nt), C.c_int32(material), ip(vertices)] + sizes(vertices) \
+        + [ip(normals)] + sizes(normals) + [ip(texcoords)] + sizes(texcoords) \
+        + [ip(idx), ip(pos), ip(nrm), ip(tc), C.byref(n_idx), C.byref(n_v), C.byref(hn), C.byref(ht)]
+    rc = fn(*args)
+    nv = int(n_v.value)
+    return rc, {"indices": idx[:int(n_idx.value)].copy(), "positions": pos[:nv].copy(),
+                "normals": nrm[:nv].copy() if hn.value else None, "texcoords": tc[:nv].copy() if ht.value else None}
+
+
+def mesh_reindex(vi, ni, ti, tri_material, material, vertices, normals, texcoords, device=0):
+    """pt_mesh_reindex: the importer's re-indexing of one (material, shape) pair on the GPU."""
+    rc, out = _reindex(lib().pt_mesh_reindex, [C.c_int(device)], vi, ni, ti, tri_material, material, vertices, normals, texcoords)
+    _check(rc)
+    return out
+
+
 def multi_plan(params, mode, n_shares, share):
     """The render calls (pt_render_params) of one share of an image split over n_shares GPUs (pt_multi_plan)."""
     n = C.c_int(0)

@@ -56,6 +56,26 @@ class Reference:
         self._check(self.lib.ref_frames_scene(C.c_float(t0), C.c_float(t1), C.byref(out)))
         return out
 
+    def parse_obj(self, path):
+        """The file as tinyobj parses it for the importer: dict of vertices, normals, texcoords, shape_first_corner,
+        vi, ni, ti (per corner), tri_material, n_materials."""
+        h = C.c_void_p()
+        sizes = (C.c_uint64 * 6)()
+        self._check(self.lib.ref_obj_parse(path.encode(), C.byref(h), sizes))
+        nv, nn, nt, nshapes, nmat, ncorners = [int(x) for x in sizes]
+        o = {"vertices": np.zeros((nv, 3), np.float32), "normals": np.zeros((nn, 3), np.float32),
+             "texcoords": np.zeros((nt, 2), np.float32), "shape_first_corner": np.zeros(nshapes + 1, np.uint64),
+             "vi": np.zeros(ncorners, np.int32), "ni": np.zeros(ncorners, np.int32), "ti": np.zeros(ncorners, np.int32),
+             "tri_material": np.zeros(ncorners // 3, np.int32), "n_materials": np.int64(nmat)}
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.ref_obj_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        self._check(self.lib.ref_obj_arrays(h, vp(o["vertices"]), vp(o["normals"]), vp(o["texcoords"]),
+                                            vp(o["shape_first_corner"]), vp(o["vi"]), vp(o["ni"]), vp(o["ti"]),
+                                            vp(o["tri_material"])))
+        self.lib.ref_obj_free.argtypes = [C.c_void_p]
+        self.lib.ref_obj_free(h)
+        return o
+
     def free_desc(self, desc_ptr):
         self.lib.ref_free_desc(desc_ptr)
 
@@ -328,6 +348,12 @@ class Oracle:
                                                        C.c_uint32(stack_limit), out, stats))
         return hits_to_numpy(out), {"box_tests": int(stats[0]), "fell_back": int(stats[1]),
                                     "deepest": int(stats[2]), "depth_hist": [int(x) for x in stats[3:67]]}
+
+    def mesh_reindex(self, vi, ni, ti, tri_material, material, vertices, normals, texcoords):
+        from path_tracing_amd.api import _reindex
+        rc, out = _reindex(self.lib.oracle_mesh_reindex, [], vi, ni, ti, tri_material, material, vertices, normals, texcoords)
+        self._check(rc)
+        return out
 
     def image_to_8bit(self, img, urq=None, flip_rows=True, math_mode=1):
         return _to_8bit(self.lib.oracle_image_to_8bit, self._check, img, urq, flip_rows, math_mode)

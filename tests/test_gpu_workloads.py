@@ -86,3 +86,38 @@ def test_frames_scene(frame, golden_dir, oracle):
         hits_dev = dev.primary_hits(cam, ph)
         assert np.mean(hits_dev["surface"] != golden_hits["surface"]) <= 5e-3
         assert rel_outliers(smp_dev, golden) <= 0.02
+
+
+def test_mesh_reindex_reproduces_the_importer(golden_dir, oracle):
+    """pt_mesh_reindex on the two OBJ files whose imports are committed: every (material, shape) pair gives the
+    index list and vertex streams the reference's importer built, bit for bit; and a seeded large case with repeated
+    and missing indices against the oracle."""
+    from test_workloads import check_reindex, reindex_cases
+    for name, o, scene in reindex_cases(golden_dir):
+        check_reindex(pt.mesh_reindex, o, scene)
+    rng = np.random.default_rng(4)
+    nt = 70000
+    vertices = rng.normal(size=(5000, 3)).astype(np.float32)
+    normals = rng.normal(size=(300, 3)).astype(np.float32)
+    texcoords = rng.random((700, 2), dtype=np.float32)
+    vi = rng.integers(0, 5000, 3 * nt).astype(np.int32)
+    ni = rng.integers(0, 300, 3 * nt).astype(np.int32)
+    ti = rng.integers(0, 4, 3 * nt).astype(np.int32)      # few distinct: many repeated triples
+    tri_material = rng.integers(-1, 3, nt).astype(np.int32)
+    for material, spoil in ((0, None), (1, "normal"), (2, "texcoord"), (-1, None), (7, None)):
+        n2, t2 = ni.copy(), ti.copy()
+        if spoil == "normal":
+            n2[3 * int(np.nonzero(tri_material == material)[0][50]) + 1] = -1
+        if spoil == "texcoord":
+            t2[3 * int(np.nonzero(tri_material == material)[0][9])] = -1
+        got = pt.mesh_reindex(vi, n2, t2, tri_material, material, vertices, normals, texcoords)
+        want = oracle.mesh_reindex(vi, n2, t2, tri_material, material, vertices, normals, texcoords)
+        assert np.array_equal(got["indices"], want["indices"])
+        assert got["positions"].tobytes() == want["positions"].tobytes()
+        for key in ("normals", "texcoords"):
+            assert (got[key] is None) == (want[key] is None), (material, key)
+            if got[key] is not None:
+                assert got[key].tobytes() == want[key].tobytes()
+        assert (got["normals"] is None) == (spoil == "normal") and (got["texcoords"] is None) == (spoil == "texcoord")
+    with pytest.raises(pt.PtError):
+        pt.mesh_reindex(vi + 5000, ni, ti, tri_material, 0, vertices, normals, texcoords)

@@ -103,3 +103,49 @@ def test_converged_images_are_present_and_sane(golden_dir):
         z = np.load(os.path.join(golden_dir, "converged_%s_96x54.npz" % name))
         assert z["image"].shape == (54, 96, 3) and np.isfinite(z["image"]).all()
         assert 0 < float(z["noise_rmse"]) < 0.02 * max(float(z["image"].mean()), 0.05)
+
+
+def reindex_cases(golden_dir):
+    """(parsed OBJ arrays, flattened scene the importer made of the same file) for the two committed OBJ imports."""
+    for name, scene_file in (("cornell", "cornell.ptscene"), ("textured", "textured.ptscene")):
+        o = np.load(os.path.join(golden_dir, "reindex_%s.npz" % name))
+        yield name, o, pt.LoadedScene(os.path.join(golden_dir, scene_file))
+
+
+def check_reindex(reindex, o, scene):
+    """Run the importer's loops (reference src/15/import.hpp:233-289: material ids -1 .. M-1, every shape) through
+    `reindex` and compare every mesh it yields with the mesh the importer itself put into the scene, stream by
+    stream, bit for bit."""
+    d = scene.desc()
+    flat = pt.FlatScene.from_desc(d)
+    first = o["shape_first_corner"].astype(np.int64)
+    k = 0
+    for material in range(-1, int(o["n_materials"])):
+        for s in range(len(first) - 1):
+            c0, c1 = first[s], first[s + 1]
+            tri_mat = o["tri_material"][c0 // 3:c1 // 3]
+            got = reindex(o["vi"][c0:c1], o["ni"][c0:c1], o["ti"][c0:c1], tri_mat, material,
+                          o["vertices"], o["normals"], o["texcoords"])
+            if len(got["indices"]) == 0:
+                assert not np.any(tri_mat == material)
+                continue
+            m = flat.meshes[k]
+            v0, nv = m.first_vertex, m.n_vertices
+            assert nv == len(got["positions"]) and 3 * m.n_triangles == len(got["indices"]), (material, s)
+            assert np.array_equal(flat.indices[m.first_index:m.first_index + 3 * m.n_triangles], got["indices"])
+            assert flat.positions[v0:v0 + nv].tobytes() == got["positions"].tobytes()
+            assert bool(m.has_normals) == (got["normals"] is not None)
+            assert bool(m.has_texcoords) == (got["texcoords"] is not None)
+            if m.has_normals:
+                assert flat.normals[v0:v0 + nv].tobytes() == got["normals"].tobytes()
+            if m.has_texcoords:
+                assert flat.texcoords[v0:v0 + nv].tobytes() == got["texcoords"].tobytes()
+            k += 1
+    assert k == len(flat.meshes)
+    return k
+
+
+def test_oracle_reindex_reproduces_the_importer(golden_dir, oracle):
+    for name, o, scene in reindex_cases(golden_dir):
+        n = check_reindex(oracle.mesh_reindex, o, scene)
+        assert n >= (8 if name == "cornell" else 17)

@@ -15,7 +15,9 @@ Run in the build container (needs /root/reference and oracle/_ref/libpt_ref.so, 
              RMSE of the benchmark line: two independent renders each; their mean is the image, their difference
              gives the noise still in it.
 
-    python tools/make_workloads.py [textured|frames|vectors|converged ...]
+  reindex    the two OBJ files as the importer's parser delivers them (inputs of the re-indexing loop).
+
+    python tools/make_workloads.py [textured|frames|vectors|converged|reindex ...]
 """
 import ctypes as C
 import math
@@ -362,10 +364,25 @@ def gen_converged(R, which):
         converged(R, "mesh1000", C.byref(d), cam, 32)
 
 
+# ------------------------------------------------------------------- reindex --
+
+def gen_reindex(R):
+    """The inputs of the importer's re-indexing loop (src/15/import.hpp:233-289) for the two OBJ files whose imported
+    scenes are committed: the files as tinyobj parses them for the importer.  The expected outputs are the meshes of
+    cornell.ptscene and textured.ptscene, which the importer itself produced."""
+    o = R.parse_obj("/root/reference/src/11/CornellBox-Original.obj")
+    np.savez_compressed(out("reindex_cornell.npz"), **o)
+    with tempfile.TemporaryDirectory() as tmp:
+        o = R.parse_obj(write_textured_obj(tmp))
+    np.savez_compressed(out("reindex_textured.npz"), **o)
+    print("reindex: %d corners" % len(o["vi"]))
+
+
 def main():
     args = sys.argv[1:]
     R = refbind.Reference()
-    steps = [a for a in args if a in ("textured", "frames", "vectors", "converged")] or ["textured", "frames", "vectors", "converged"]
+    steps = [a for a in args if a in ("textured", "frames", "vectors", "converged", "reindex")] \
+        or ["textured", "frames", "vectors", "converged", "reindex"]
     which = [a for a in args if a.startswith("only=")]
     which = which[0][5:].split(",") if which else []
     if "textured" in steps:
@@ -376,6 +393,8 @@ def main():
         gen_vectors(R)
     if "converged" in steps:
         gen_converged(R, which)
+    if "reindex" in steps:
+        gen_reindex(R)
 
 
 if __name__ == "__main__":
