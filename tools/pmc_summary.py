@@ -42,4 +42,11 @@ for k, v in sorted(agg.items(), key=lambda kv: -dur[kv[0]]):
             parts.append("valu_insts/wave=%.0f" % (v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1)))
         if "SQ_WAVES" in v:
             parts.append("wavecycles/wave=%.0f(x4 cyc)" % (wc / max(v["SQ_WAVES"], 1)))
+        if "GRBM_GUI_ACTIVE" in v and "SQ_INSTS_VALU" in v:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 vector instruction holds its SIMD for 4 cycles
+            # (1024 SIMDs on the chip)
+            cycles = v["GRBM_GUI_ACTIVE"] / cnt[k] / 8.0
+            secs = dur[k] / cnt[k] / 1e9
+            parts.append("clock=%.2fGHz" % (cycles / secs / 1e9))
+            parts.append("valu_issue_busy=%.2f" % (v["SQ_INSTS_VALU"] / cnt[k] / 1024.0 * 4.0 / cycles))
         print("      fraction of wave-cycles: " + " ".join(parts))
