@@ -1,6 +1,6 @@
 """The benchmark's other configurations at their full sizes, through properties that need no full-size render
-on the CPU: the 2 M-triangle mesh at 1920x1080, the textured scene at 3840x2160 with path depth 32, and a frame
-of the animated scene at 1920x1080.  (The Cornell configuration's counterpart is
+on the CPU: the 2 M-triangle mesh at 1920x1080, the textured multi-material OBJ scene at 3840x2160 with path depth 32
+(also split over two scene handles), and a frame of the reference's animation scene at 1920x1080.  (The Cornell configuration's counterpart is
 test_gpu_parity.py::test_full_size_properties.)"""
 import ctypes as C
 import os
@@ -66,34 +66,45 @@ def test_two_million_triangles(oracle):
     assert np.mean(bits(again) != bits(fast)) <= 1e-3  # paths that met a tie go another way
 
 
-def test_textured_scene_at_4k(oracle):
-    """3840x2160, path depth 32: a tile of the full render bit for bit, a window against the oracle."""
-    s, cam, _ = scenes.build("materials")
-    d = s.desc()
+def test_textured_scene_at_4k(golden_dir, oracle):
+    """The textured multi-material OBJ scene at 3840x2160, 4 of the benchmark's 512 samples, path depth 32: a tile of
+    the full render bit for bit, a window against the oracle; the same image from two scene handles splitting it by
+    tiles (pt_render_multi), bit for bit; sums over sample ranges against the sum over all."""
+    scene = pt.LoadedScene(os.path.join(golden_dir, "textured.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "textured.ptcam"))
     W, H = 3840, 2160
-    with pt.DeviceScene(s) as dev:
-        p = pt.make_params(W, H, 2, seed=3, max_path_segments=32)
+    kw = dict(seed=3, max_path_segments=32, samples=(0, 4), flags=pt.abi.PT_RENDER_SUM_ONLY)
+    with pt.DeviceScene(scene) as dev, pt.DeviceScene(scene) as dev2:
+        p = pt.make_params(W, H, 23, **kw)
         full = dev.render(cam, p)
-        assert np.isfinite(full).all()
+        assert np.isfinite(full).all() and full.mean() > 0.1
         tile = np.zeros_like(full)
-        q = pt.make_params(W, H, 2, seed=3, max_path_segments=32, tile=(1900, 1000, 2028, 1064))
+        q = pt.make_params(W, H, 23, tile=(1900, 1000, 2028, 1064), **kw)
         dev.render(cam, q, out=tile)
         assert same_bits(tile[1000:1064, 1900:2028], full[1000:1064, 1900:2028])
-    want = oracle.render(C.byref(d), cam, q, math_mode=1)
+        assert same_bits(pt.render_multi([dev, dev2], cam, p, pt.abi.PT_SHARD_TILES), full)
+        halves = [dev.render(cam, pt.make_params(W, H, 23, seed=3, max_path_segments=32, samples=r,
+                                                 flags=pt.abi.PT_RENDER_SUM_ONLY)) for r in ((0, 1), (1, 4))]
+        assert np.allclose(halves[0] + halves[1], full, rtol=1e-5, atol=1e-6)
+    want = oracle.render(scene.ptr, cam, q, math_mode=1)
     assert same_bits(tile[1000:1064, 1900:2028], want[1000:1064, 1900:2028])
 
 
-def test_animated_frame_at_1080p(oracle):
-    """One frame of the animation at 1920x1080 with its own tree (host-built, then device-built): a window of the
-    image against the oracle."""
-    s, cam, _ = scenes.build("animated")
-    t0, t1 = 3 / 25.0, 4 / 25.0
+def test_animation_frame_at_1080p(golden_dir, oracle):
+    """One frame (number 100 of 240) of the reference's animation scene at 1920x1080 with its own tree (the
+    reference's builder, then the device's): a window of the image against the oracle."""
+    from path_tracing_amd import workloads
+    loaded = pt.LoadedScene(os.path.join(golden_dir, "frames.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "frames.ptcam"))
+    s = pt.FlatScene.from_desc(loaded.desc())
+    t0, t1 = workloads.frame_interval(100)
     W, H = 1920, 1080
-    q = pt.make_params(W, H, 2, seed=11, t0=t0, t1=t1, tile=(900, 500, 1028, 564))
-    with pt.DeviceScene(s) as dev:
+    q = pt.make_params(W, H, 2, seed=142, t0=t0, t1=t1, tile=(900, 500, 1028, 564))
+    with pt.DeviceScene(loaded) as dev:
         dev.update_bvh(s.build_bvh(t0, t1))
         d = s.desc()
-        full = dev.render(cam, pt.make_params(W, H, 2, seed=11, t0=t0, t1=t1))
+        full = dev.render(cam, pt.make_params(W, H, 2, seed=142, t0=t0, t1=t1))
+        assert np.isfinite(full).all() and full.mean() > 0.1
         want = oracle.render(C.byref(d), cam, q, math_mode=1)
         assert same_bits(full[500:564, 900:1028], want[500:564, 900:1028])
         dev.build_bvh_device(t0, t1)
