@@ -420,11 +420,16 @@ int pt_image_to_8bit(int device, const float* rgb, int width, int height, float 
  * BVHTreeLinear::flattenBVH produce on one host thread (reference
  * src/15/bvh.hpp:36-108,146-176) and src/07/pathtracer-frames.cpp:209-211
  * repeats per frame.  Surface bounds are the reference's (Surface::aabb,
- * surface_triangle.hpp:32-63, surface_sphere.hpp:50-69); the tree is a
- * Morton-order radix tree, not the reference's sorted-sweep tree, so rays
- * find the same surface at the same distance except where two surfaces are
- * hit at exactly equal distances (the walk order decides those).  A scene may
- * be created with n_bvh_nodes == 0 and get its first tree here.
+ * surface_triangle.hpp:32-63, surface_sphere.hpp:50-69); the tree is built
+ * top-down with the reference's surface-area criterion (bvh.hpp:60-96) over
+ * 32 bins per axis, and over every split of the sorted order below 65
+ * surfaces -- not the reference's one-axis sorted sweep, so rays find the
+ * same surface at the same distance except where two surfaces are hit at
+ * exactly equal distances (the walk order decides those).  Equal inputs give
+ * equal trees.  With PT_BVH_BUILDER=morton in the environment the tree is a
+ * radix tree over Morton codes instead: a tenth of the build time, slower to
+ * walk.  A scene may be created with n_bvh_nodes == 0 and get its first tree
+ * here.
  * pt_scene_get_bvh copies the installed tree out in the layout of
  * pt_scene_desc.bvh_nodes (call with out_nodes == NULL to get the count). */
 int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_stream);

@@ -8,26 +8,36 @@
 // (`nodes` in the reference's pre-order layout with escape links, and the 32-byte rows of the
 // nearer-child-first walk); nothing but the root box crosses to the host.
 //
-//   1 surfaceBoxesKernel  Surface::aabb(t0, t1) per surface with the reference's arithmetic
-//                         (surface_triangle.hpp:32-63, surface_sphere.hpp:50-69: 16 poses of a
-//                         moving surface), and per block the bounds of the box centres
-//   2 mortonKernel        63-bit Morton code of each box centre inside the centre bounds
-//   3 rocprim radix sort  (code, surface) pairs
-//   4 hierarchyKernel     the binary radix tree over the sorted codes (Karras 2012): node i
-//                         finds its range of leaves and its split by counting common prefix
-//                         bits; equal codes are told apart by their position
-//   5 refitKernel         boxes of the inner nodes bottom-up: the second child to arrive at a
-//                         node merges and goes on
-//   6 layoutKernel        every node's place in pre-order: 2 * (first leaf of its range) + the
-//                         number of left turns on the way down from the root; writes `nodes`
-//   7 wideRowsKernel      the rows of the nearer-child-first walk (DevScene::wide)
+//   surfaceBoxesKernel   Surface::aabb(t0, t1) per surface with the reference's arithmetic
+//                        (surface_triangle.hpp:32-63, surface_sphere.hpp:50-69: 16 poses of a
+//                        moving surface), and per block the bounds of the boxes (or of their centres)
 //
-// The tree is not the reference's tree (that one needs the sequential sort per node), so the
+// Two builders share that step and the tables they fill.  The default is the surface-area builder
+// (the reference's criterion, bvh.hpp:60-96, applied to 32 bins per axis for large nodes and to every
+// split of the sorted order for nodes of up to 64 surfaces; see "the surface-area builder" below).
+// PT_BVH_BUILDER=morton selects the radix tree, which is ten times quicker to build and up to half
+// as fast to walk:
+//   mortonKernel        63-bit Morton code of each box centre inside the centre bounds
+//   rocprim radix sort  (code, surface) pairs
+//   hierarchyKernel     the binary radix tree over the sorted codes (Karras 2012): node i
+//                       finds its range of leaves and its split by counting common prefix
+//                       bits; equal codes are told apart by their position
+//   refitKernel         boxes of the inner nodes bottom-up: the second child to arrive at a
+//                       node merges and goes on
+//   layoutKernel        every node's place in pre-order: 2 * (first leaf of its range) + the
+//                       number of left turns on the way down from the root; writes `nodes`
+//   wideRowsKernel      the rows of the nearer-child-first walk (DevScene::wide)
+//
+// Neither tree is the reference's tree (that one needs the sequential sort per node), so the
 // walk order differs and with it which of two surfaces hit at exactly the same distance wins;
 // apart from such ties every ray finds the same surface at the same distance, because leaf
 // boxes and surface tests are the reference's.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstring>
@@ -74,7 +84,7 @@ PT_DEV void surfaceBoxAt(const DevScene& sc, uint32_t sid, uint32_t kind, float 
 constexpr uint32_t kBlock = 256;
 
 __global__ void __launch_bounds__(kBlock) surfaceBoxesKernel(DevScene sc, float t0, float t1, float4* __restrict__ leafBox,
-                                                             float4* __restrict__ blockBounds)
+                                                             float4* __restrict__ blockBounds, int boundsOfBoxes)
 {
     __shared__ float red[6][kBlock / 64];
     const uint32_t sid = blockIdx.x * kBlock + threadIdx.x;
@@ -96,10 +106,10 @@ __global__ void __launch_bounds__(kBlock) surfaceBoxesKernel(DevScene sc, float 
         leafBox[2 * size_t(sid) + 0] = make_float4(lo.x, lo.y, lo.z, hi.x);
         leafBox[2 * size_t(sid) + 1] = make_float4(hi.y, hi.z, 0.0f, 0.0f);
         const V3 c = v3(mixf(lo.x, hi.x, 0.5f), mixf(lo.y, hi.y, 0.5f), mixf(lo.z, hi.z, 0.5f));
-        cLo = c;
-        cHi = c;
+        cLo = boundsOfBoxes ? lo : c;
+        cHi = boundsOfBoxes ? hi : c;
     }
-    // bounds of the block's centres: wave reduction by lane shuffles, then one lane per block
+    // bounds of the block's centres (or boxes): wave reduction by lane shuffles, then one lane per block
     float v[6] = { cLo.x, cLo.y, cLo.z, cHi.x, cHi.y, cHi.z };
     for (int k = 0; k < 6; k++) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -376,6 +386,533 @@ __global__ void __launch_bounds__(kBlock) wideRowsKernel(DevScene sc, const floa
     wide[2 * size_t(row) + 1] = make_uint4(w[4], w[5], link[0], link[1]);
 }
 
+// ---- the surface-area builder -------------------------------------------------------------------------------
+// Top-down, one tree level per pass, every node written straight to its final place: a node at place P over the
+// surfaces at places [b, b + m) of the work order has its first child at P + 1 and, with mL surfaces in the first
+// child, its second child at P + 2 mL; its row of the `wide` table is P - b.
+//   nodes of more than 64 surfaces: per pass, every surface adds its box to one of 32 bins per axis of its node
+//     (binKernel; per-block bins in LDS where a block lies inside one node), the node picks the plane between bins
+//     with the smallest  area(left) * count(left) + area(right) * count(right)  (splitKernel), and a stable
+//     partition by a prefix sum over the whole order moves the surfaces (flagKernel, scan, scatterKernel);
+//   nodes of up to 64 surfaces: one wave each (smallSubtreesKernel) builds the whole subtree in LDS, trying every
+//     split of the surfaces sorted by centre along every axis.
+// Equal inputs give equal trees: the bins are filled by order-independent integer atomics, the partition is
+// stable, and the order in which nodes are numbered inside a pass does not reach the output.
+constexpr int kBins = 32;
+constexpr int kBinWords = 7; // count, lo xyz, hi xyz (the latter as order-preserving keys)
+constexpr int kNodeBinWords = 3 * kBins * kBinWords;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kSmallNode = 64;
+constexpr uint32_t kByPosition = 3; // SplitRec::axis of a node that is halved by place
+
+struct ActiveNode {
+    uint32_t place, begin, count, pad;
+    float lo[3], hi[3]; // what the bins span: the node's box, or a box around it
+    uint32_t pad2[2];
+};
+struct SplitRec {
+    uint32_t axis, plane, nLeft, pad;
+    uint32_t child[2]; // number of the child in the next pass's list, or kNone
+    uint32_t pad2[2];
+};
+struct SmallTask {
+    uint32_t place, begin, count, pad;
+};
+
+// floats as unsigned keys of the same order (for integer atomic min / max)
+PT_DEV uint32_t orderKey(float f)
+{
+    const uint32_t u = fbits(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+PT_DEV float keyFloat(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+PT_DEV int binOf(float c, float lo, float hi)
+{
+    const float ext = hi - lo;
+    float f = ext > 0.0f ? (c - lo) * (float(kBins) / ext) : 0.0f;
+    f = fminf(fmaxf(f, 0.0f), float(kBins - 1)); // (NaN lands in bin 0)
+    return int(f);
+}
+
+PT_DEV float halfArea(const float* lo, const float* hi)
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(kBlock) sahStartKernel(const float4* __restrict__ bounds, uint32_t n, ActiveNode* __restrict__ active,
+                                                         uint32_t* __restrict__ idx, uint32_t* __restrict__ nodeAt,
+                                                         SmallTask* __restrict__ small, uint32_t* __restrict__ counters)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < n) {
+        idx[p] = p;
+        nodeAt[p] = n > kSmallNode ? 0u : kNone;
+    }
+    if (p == 0 && n <= kSmallNode) {
+        const SmallTask t = { 0u, 0u, n, 0u };
+        small[0] = t;
+        counters[1] = 1u;
+    } else if (p == 0) {
+        const float4 a = bounds[0], b = bounds[1];
+        ActiveNode r = {};
+        r.count = n;
+        r.lo[0] = a.x; r.lo[1] = a.y; r.lo[2] = a.z;
+        r.hi[0] = a.w; r.hi[1] = b.x; r.hi[2] = b.y;
+        active[0] = r;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) clearBinsKernel(uint32_t* __restrict__ bins, size_t words)
+{
+    const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+    if (i < words) {
+        const uint32_t w = uint32_t(i % kBinWords);
+        bins[i] = w == 0 ? 0u : (w <= 3 ? 0xFFFFFFFFu : 0u);
+    }
+}
+
+template <typename Add, typename Min, typename Max>
+PT_DEV void addToBins(uint32_t* bins, const ActiveNode& nd, float4 b0, float4 b1, Add add, Min mn, Max mx)
+{
+    const float lo[3] = { b0.x, b0.y, b0.z }, hi[3] = { b0.w, b1.x, b1.y };
+    uint32_t klo[3], khi[3];
+    for (int a = 0; a < 3; a++) {
+        klo[a] = orderKey(lo[a]);
+        khi[a] = orderKey(hi[a]);
+    }
+    for (int a = 0; a < 3; a++) {
+        const int bin = binOf(mixf(lo[a], hi[a], 0.5f), nd.lo[a], nd.hi[a]);
+        uint32_t* w = bins + (a * kBins + bin) * kBinWords;
+        add(w);
+        for (int k = 0; k < 3; k++) {
+            mn(w + 1 + k, klo[k]);
+            mx(w + 4 + k, khi[k]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) binKernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ nodeAt,
+                                                    const ActiveNode* __restrict__ active, const float4* __restrict__ leafBox,
+                                                    uint32_t* __restrict__ bins)
+{
+    __shared__ uint32_t sBins[kNodeBinWords];
+    const uint32_t first = blockIdx.x * kBlock, last = min(first + kBlock, n) - 1u;
+    const uint32_t p = first + threadIdx.x;
+    // a node owns a run of places: the same live node at both ends of the block means the block lies inside it
+    const uint32_t aFirst = nodeAt[first];
+    const bool inOneNode = aFirst != kNone && aFirst == nodeAt[last];
+    if (inOneNode) {
+        for (uint32_t i = threadIdx.x; i < uint32_t(kNodeBinWords); i += kBlock) {
+            const uint32_t w = i % kBinWords;
+            sBins[i] = w == 0 ? 0u : (w <= 3 ? 0xFFFFFFFFu : 0u);
+        }
+        __syncthreads();
+        if (p < n) {
+            const uint32_t s = idx[p];
+            addToBins(sBins, active[aFirst], leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
+                      [](uint32_t* w) { atomicAdd(w, 1u); }, [](uint32_t* w, uint32_t v) { atomicMin(w, v); },
+                      [](uint32_t* w, uint32_t v) { atomicMax(w, v); });
+        }
+        __syncthreads();
+        uint32_t* g = bins + size_t(aFirst) * kNodeBinWords;
+        for (uint32_t i = threadIdx.x; i < uint32_t(kNodeBinWords); i += kBlock) {
+            const uint32_t w = i % kBinWords, v = sBins[i];
+            if (w == 0) {
+                if (v)
+                    atomicAdd(g + i, v);
+            } else if (w <= 3) {
+                if (v != 0xFFFFFFFFu)
+                    atomicMin(g + i, v);
+            } else if (v) {
+                atomicMax(g + i, v);
+            }
+        }
+        return;
+    }
+    if (p >= n)
+        return;
+    const uint32_t a = nodeAt[p];
+    if (a == kNone)
+        return;
+    const uint32_t s = idx[p];
+    addToBins(bins + size_t(a) * kNodeBinWords, active[a], leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
+              [](uint32_t* w) { atomicAdd(w, 1u); }, [](uint32_t* w, uint32_t v) { atomicMin(w, v); },
+              [](uint32_t* w, uint32_t v) { atomicMax(w, v); });
+}
+
+struct BinBox {
+    float lo[3], hi[3];
+    uint32_t count;
+};
+PT_DEV void clearBox(BinBox& b)
+{
+    const float inf = __builtin_huge_valf();
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = inf;
+        b.hi[k] = -inf;
+    }
+    b.count = 0;
+}
+PT_DEV void addBin(BinBox& b, const uint32_t* __restrict__ w)
+{
+    const uint32_t c = w[0];
+    if (c == 0)
+        return;
+    b.count += c;
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = fminf(b.lo[k], keyFloat(w[1 + k]));
+        b.hi[k] = fmaxf(b.hi[k], keyFloat(w[4 + k]));
+    }
+}
+
+// One block of 128 threads per live node; thread (axis, plane) prices the split between bins plane - 1 and plane.
+__global__ void __launch_bounds__(128) splitKernel(const ActiveNode* __restrict__ active, const uint32_t* __restrict__ bins,
+                                                   int halveAll, SplitRec* __restrict__ splits, ActiveNode* __restrict__ nextActive,
+                                                   SmallTask* __restrict__ small, uint32_t* __restrict__ counters /* [0] next, [1] small */,
+                                                   float4* __restrict__ nodes, uint32_t* __restrict__ firstLeaf)
+{
+    __shared__ unsigned long long best;
+    const uint32_t a = blockIdx.x;
+    const uint32_t axis = threadIdx.x / kBins, plane = threadIdx.x % kBins;
+    const uint32_t* nb = bins + size_t(a) * kNodeBinWords;
+    if (threadIdx.x == 0)
+        best = ~0ull;
+    __syncthreads();
+    BinBox L, R;
+    clearBox(L);
+    clearBox(R);
+    unsigned long long key = ~0ull;
+    if (axis < 3 && plane > 0 && !halveAll) {
+        for (uint32_t k = 0; k < uint32_t(kBins); k++)
+            addBin(k < plane ? L : R, nb + (axis * kBins + k) * kBinWords);
+        if (L.count > 0 && R.count > 0) {
+            const float cost = halfArea(L.lo, L.hi) * float(L.count) + halfArea(R.lo, R.hi) * float(R.count);
+            if (cost >= 0.0f && cost < __builtin_huge_valf())
+                key = ((unsigned long long) fbits(cost) << 32) | (axis << 8) | plane;
+        }
+    }
+    if (key != ~0ull)
+        atomicMin(&best, key);
+    __syncthreads();
+    const unsigned long long win = best;
+    const bool byPlace = win == ~0ull;
+    if (byPlace ? threadIdx.x != 0 : key != win)
+        return;
+    const ActiveNode nd = active[a];
+    uint32_t nLeft;
+    if (byPlace) {
+        // no plane separates the centres (or the tree is too deep already): halve the run of places; the halves
+        // take this node's span for their bins, and their boxes come out of their own bins in the next pass
+        clearBox(L);
+        clearBox(R);
+        for (uint32_t k = 0; k < uint32_t(kBins); k++)
+            addBin(L, nb + k * kBinWords);
+        nLeft = nd.count / 2;
+    } else {
+        nLeft = L.count;
+    }
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = fminf(L.lo[k], R.lo[k]);
+        hi[k] = fmaxf(L.hi[k], R.hi[k]);
+    }
+    const uint32_t second = nd.place + 2u * nLeft;
+    nodes[2 * size_t(nd.place) + 0] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+    nodes[2 * size_t(nd.place) + 1] = make_float4(hi[1], hi[2], __uint_as_float(nd.place + 2u * nd.count - 1u), __uint_as_float(kInnerBit | second));
+    firstLeaf[nd.place] = nd.begin;
+    SplitRec sp = {};
+    sp.axis = byPlace ? kByPosition : axis;
+    sp.plane = plane;
+    sp.nLeft = nLeft;
+    for (int c = 0; c < 2; c++) {
+        const uint32_t count = c == 0 ? nLeft : nd.count - nLeft;
+        const uint32_t place = c == 0 ? nd.place + 1u : second;
+        const uint32_t begin = c == 0 ? nd.begin : nd.begin + nLeft;
+        if (count > kSmallNode) {
+            const uint32_t slot = atomicAdd(&counters[0], 1u);
+            ActiveNode ch = {};
+            ch.place = place;
+            ch.begin = begin;
+            ch.count = count;
+            const BinBox& bx = c == 0 ? L : R;
+            for (int k = 0; k < 3; k++) {
+                ch.lo[k] = byPlace ? nd.lo[k] : bx.lo[k];
+                ch.hi[k] = byPlace ? nd.hi[k] : bx.hi[k];
+            }
+            nextActive[slot] = ch;
+            sp.child[c] = slot;
+        } else {
+            const uint32_t slot = atomicAdd(&counters[1], 1u);
+            SmallTask t = { place, begin, count, 0u };
+            small[slot] = t;
+            sp.child[c] = kNone;
+        }
+    }
+    splits[a] = sp;
+}
+
+__global__ void __launch_bounds__(kBlock) flagKernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ nodeAt,
+                                                     const ActiveNode* __restrict__ active, const SplitRec* __restrict__ splits,
+                                                     const float4* __restrict__ leafBox, uint32_t* __restrict__ flags)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint32_t a = nodeAt[p];
+    uint32_t left = 0;
+    if (a != kNone) {
+        const SplitRec sp = splits[a];
+        if (sp.axis == kByPosition) {
+            left = p - active[a].begin < sp.nLeft ? 1u : 0u;
+        } else {
+            const uint32_t s = idx[p];
+            const float4 b0 = leafBox[2 * size_t(s)], b1 = leafBox[2 * size_t(s) + 1];
+            const float lo = sp.axis == 0 ? b0.x : (sp.axis == 1 ? b0.y : b0.z);
+            const float hi = sp.axis == 0 ? b0.w : (sp.axis == 1 ? b1.x : b1.y);
+            const ActiveNode& nd = active[a];
+            left = uint32_t(binOf(mixf(lo, hi, 0.5f), nd.lo[sp.axis], nd.hi[sp.axis])) < sp.plane ? 1u : 0u;
+        }
+    }
+    flags[p] = left;
+}
+
+__global__ void __launch_bounds__(kBlock) scatterKernel(uint32_t n, const uint32_t* __restrict__ idxIn, const uint32_t* __restrict__ nodeAtIn,
+                                                        const ActiveNode* __restrict__ active, const SplitRec* __restrict__ splits,
+                                                        const uint32_t* __restrict__ flags, const uint32_t* __restrict__ leftBefore,
+                                                        uint32_t* __restrict__ idxOut, uint32_t* __restrict__ nodeAtOut)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint32_t a = nodeAtIn[p], s = idxIn[p];
+    if (a == kNone) {
+        idxOut[p] = s;
+        nodeAtOut[p] = kNone;
+        return;
+    }
+    const uint32_t begin = active[a].begin;
+    const SplitRec sp = splits[a];
+    const uint32_t rank = leftBefore[p] - leftBefore[begin]; // surfaces of the node before this one that go left
+    const bool left = flags[p] != 0;
+    const uint32_t q = left ? begin + rank : begin + sp.nLeft + (p - begin - rank);
+    idxOut[q] = s;
+    nodeAtOut[q] = sp.child[left ? 0 : 1];
+}
+
+// One wave per node of up to 64 surfaces: the whole subtree, level by level, all nodes of a level at once.
+// Lane = place inside the run.  A lane's candidate split of its node sends to the first child every surface
+// whose centre comes before the lane's own along the axis (ties by place), so every way of cutting the sorted
+// order is tried on every axis, as in a full sweep.
+__global__ void __launch_bounds__(64) smallSubtreesKernel(const SmallTask* __restrict__ tasks, const uint32_t* __restrict__ idx,
+                                                          const float4* __restrict__ leafBox, float4* __restrict__ nodes,
+                                                          uint32_t* __restrict__ firstLeaf)
+{
+    __shared__ float sBox[64][8];           // lo xyz, hi xyz, surface
+    __shared__ unsigned long long sBest[64]; // per node (by its first lane): cheapest candidate
+    __shared__ float sHalves[64][12];        // per node: boxes of the winner's two halves
+    const SmallTask task = tasks[blockIdx.x];
+    const uint32_t lane = threadIdx.x, m = task.count;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+    uint32_t sid = 0;
+    if (lane < m) {
+        sid = idx[task.begin + lane];
+        const float4 b0 = leafBox[2 * size_t(sid)], b1 = leafBox[2 * size_t(sid) + 1];
+        lo[0] = b0.x; lo[1] = b0.y; lo[2] = b0.z;
+        hi[0] = b0.w; hi[1] = b1.x; hi[2] = b1.y;
+    }
+    // my node: lanes [nb, nb + nm) at place nP, box nlo..nhi
+    uint32_t nb = 0, nm = lane < m ? m : 0u, nP = task.place;
+    float nlo[3], nhi[3];
+    for (int k = 0; k < 3; k++) {
+        float a = lo[k], b = hi[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            a = fminf(a, __shfl_xor(a, off, 64));
+            b = fmaxf(b, __shfl_xor(b, off, 64));
+        }
+        nlo[k] = a;
+        nhi[k] = b;
+    }
+    for (;;) {
+        const bool open = nm > 1;
+        if (__ballot(open) == 0ull)
+            break;
+        for (int k = 0; k < 3; k++) {
+            sBox[lane][k] = lo[k];
+            sBox[lane][3 + k] = hi[k];
+        }
+        sBox[lane][6] = __uint_as_float(sid);
+        if (open && lane == nb)
+            sBest[nb] = ~0ull;
+        __syncthreads();
+        float c[3];
+        for (int k = 0; k < 3; k++)
+            c[k] = mixf(lo[k], hi[k], 0.5f);
+        float Llo[3][3], Lhi[3][3], Rlo[3][3], Rhi[3][3];
+        uint32_t nL[3] = { 0, 0, 0 };
+        for (int a = 0; a < 3; a++)
+            for (int k = 0; k < 3; k++) {
+                Llo[a][k] = inf; Lhi[a][k] = -inf;
+                Rlo[a][k] = inf; Rhi[a][k] = -inf;
+            }
+        for (uint32_t k = 0; __ballot(open && k < nm) != 0ull; k++) {
+            if (open && k < nm) {
+                const uint32_t j = nb + k;
+                float jlo[3], jhi[3];
+                for (int d = 0; d < 3; d++) {
+                    jlo[d] = sBox[j][d];
+                    jhi[d] = sBox[j][3 + d];
+                }
+                for (int a = 0; a < 3; a++) {
+                    const float cj = mixf(jlo[a], jhi[a], 0.5f);
+                    const bool left = cj < c[a] || (cj == c[a] && j < lane);
+                    nL[a] += left ? 1u : 0u;
+                    for (int d = 0; d < 3; d++) {
+                        Llo[a][d] = left ? fminf(Llo[a][d], jlo[d]) : Llo[a][d];
+                        Lhi[a][d] = left ? fmaxf(Lhi[a][d], jhi[d]) : Lhi[a][d];
+                        Rlo[a][d] = left ? Rlo[a][d] : fminf(Rlo[a][d], jlo[d]);
+                        Rhi[a][d] = left ? Rhi[a][d] : fmaxf(Rhi[a][d], jhi[d]);
+                    }
+                }
+            }
+        }
+        unsigned long long key = ~0ull;
+        if (open) {
+            for (uint32_t a = 0; a < 3; a++) {
+                if (nL[a] == 0)
+                    continue;
+                const float cost = halfArea(Llo[a], Lhi[a]) * float(nL[a]) + halfArea(Rlo[a], Rhi[a]) * float(nm - nL[a]);
+                if (cost >= 0.0f && cost < inf) {
+                    const unsigned long long k2 = ((unsigned long long) fbits(cost) << 32) | (lane << 2) | a;
+                    key = k2 < key ? k2 : key;
+                }
+            }
+            if (key != ~0ull)
+                atomicMin(&sBest[nb], key);
+        }
+        __syncthreads();
+        bool left = false;
+        uint32_t nLeft = 0;
+        if (open) {
+            const unsigned long long win = sBest[nb];
+            if (win == ~0ull) {
+                // no candidate (centres that do not compare): halve the run of lanes; the first lane of the node
+                // works out the two boxes
+                nLeft = nm / 2;
+                left = lane - nb < nLeft;
+                if (lane == nb) {
+                    float h[12];
+                    for (int d = 0; d < 3; d++) {
+                        h[d] = inf; h[3 + d] = -inf; h[6 + d] = inf; h[9 + d] = -inf;
+                    }
+                    for (uint32_t k = 0; k < nm; k++) {
+                        const int o = k < nLeft ? 0 : 6;
+                        for (int d = 0; d < 3; d++) {
+                            h[o + d] = fminf(h[o + d], sBox[nb + k][d]);
+                            h[o + 3 + d] = fmaxf(h[o + 3 + d], sBox[nb + k][3 + d]);
+                        }
+                    }
+                    for (int d = 0; d < 12; d++)
+                        sHalves[nb][d] = h[d];
+                }
+            } else {
+                const uint32_t wl = uint32_t(win >> 2) & 63u, wa = uint32_t(win) & 3u;
+                const float cw = mixf(sBox[wl][wa], sBox[wl][3 + wa], 0.5f);
+                const float cm = wa == 0 ? c[0] : (wa == 1 ? c[1] : c[2]);
+                left = cm < cw || (cm == cw && lane < wl);
+                if (lane == wl) {
+                    for (int d = 0; d < 3; d++) {
+                        sHalves[nb][d] = wa == 0 ? Llo[0][d] : (wa == 1 ? Llo[1][d] : Llo[2][d]);
+                        sHalves[nb][3 + d] = wa == 0 ? Lhi[0][d] : (wa == 1 ? Lhi[1][d] : Lhi[2][d]);
+                        sHalves[nb][6 + d] = wa == 0 ? Rlo[0][d] : (wa == 1 ? Rlo[1][d] : Rlo[2][d]);
+                        sHalves[nb][9 + d] = wa == 0 ? Rhi[0][d] : (wa == 1 ? Rhi[1][d] : Rhi[2][d]);
+                    }
+                }
+            }
+        }
+        // stable partition inside each node: new lane of every surface
+        const unsigned long long leftMask = __ballot(open && left);
+        uint32_t to = lane;
+        if (open) {
+            const unsigned long long nodeMask = (nm == 64u ? ~0ull : ((1ull << nm) - 1ull)) << nb;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            nLeft = uint32_t(__popcll(leftMask & nodeMask));
+            to = left ? nb + uint32_t(__popcll(leftMask & nodeMask & below))
+                      : nb + nLeft + uint32_t(__popcll(~leftMask & nodeMask & below));
+        }
+        __syncthreads();
+        if (open) {
+            if (lane == nb) {
+                const uint32_t second = nP + 2u * nLeft;
+                nodes[2 * size_t(nP) + 0] = make_float4(nlo[0], nlo[1], nlo[2], nhi[0]);
+                nodes[2 * size_t(nP) + 1] = make_float4(nhi[1], nhi[2], __uint_as_float(nP + 2u * nm - 1u), __uint_as_float(kInnerBit | second));
+                firstLeaf[nP] = task.begin + nb;
+            }
+            // what this lane's place belongs to from now on
+            const bool first = lane - nb < nLeft;
+            for (int d = 0; d < 3; d++) {
+                nlo[d] = sHalves[nb][(first ? 0 : 6) + d];
+                nhi[d] = sHalves[nb][(first ? 3 : 9) + d];
+            }
+            nP = first ? nP + 1u : nP + 2u * nLeft;
+            const uint32_t oldNb = nb;
+            nb = first ? oldNb : oldNb + nLeft;
+            nm = first ? nLeft : nm - nLeft;
+        }
+        __syncthreads();
+        for (int k = 0; k < 3; k++) {
+            sBox[to][k] = lo[k];
+            sBox[to][3 + k] = hi[k];
+        }
+        sBox[to][6] = __uint_as_float(sid);
+        __syncthreads();
+        for (int k = 0; k < 3; k++) {
+            lo[k] = sBox[lane][k];
+            hi[k] = sBox[lane][3 + k];
+        }
+        sid = fbits(sBox[lane][6]);
+        __syncthreads();
+    }
+    if (lane < m) {
+        nodes[2 * size_t(nP) + 0] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        nodes[2 * size_t(nP) + 1] = make_float4(hi[1], hi[2], __uint_as_float(nP + 1u), __uint_as_float(sid));
+    }
+}
+
+// the rows of the nearer-child-first walk from a finished pre-order table; firstLeaf[P] = leaves before place P
+__global__ void __launch_bounds__(kBlock) rowsFromNodesKernel(DevScene sc, const float4* __restrict__ nodes, const uint32_t* __restrict__ firstLeaf,
+                                                              uint32_t nNodes, V3 base, V3 step, uint4* __restrict__ wide)
+{
+    const uint32_t P = blockIdx.x * kBlock + threadIdx.x;
+    if (P >= nNodes)
+        return;
+    const uint32_t mine = fbits(nodes[2 * size_t(P) + 1].w);
+    if (!(mine & kInnerBit))
+        return;
+    const uint32_t b = firstLeaf[P], second = mine & ~kInnerBit, nLeft = (second - P) / 2u;
+    const uint32_t child[2] = { P + 1u, second }, childFirst[2] = { b, b + nLeft };
+    uint32_t w[6], link[2];
+    for (int c = 0; c < 2; c++) {
+        const uint32_t at = child[c];
+        const float4 b0 = nodes[2 * size_t(at)], b1 = nodes[2 * size_t(at) + 1];
+        const uint32_t qlx = gridBelow(b0.x, base.x, step.x), qly = gridBelow(b0.y, base.y, step.y), qlz = gridBelow(b0.z, base.z, step.z);
+        const uint32_t qhx = gridAbove(b0.w, base.x, step.x), qhy = gridAbove(b1.x, base.y, step.y), qhz = gridAbove(b1.y, base.z, step.z);
+        w[3 * c + 0] = qlx | (qly << 16);
+        w[3 * c + 1] = qlz | (qhx << 16);
+        w[3 * c + 2] = qhy | (qhz << 16);
+        const uint32_t l = fbits(b1.w);
+        if (l & kInnerBit)
+            link[c] = kInnerBit | (at - childFirst[c]);
+        else
+            link[c] = fbits(sc.surf[3 * size_t(l)].w) == kTriStatic ? l : (kLeafRowBit | at);
+    }
+    const uint32_t row = P - b;
+    wide[2 * size_t(row) + 0] = make_uint4(w[0], w[1], w[2], w[3]);
+    wide[2 * size_t(row) + 1] = make_uint4(w[4], w[5], link[0], link[1]);
+}
+
 __global__ void singleLeafKernel(const float4* __restrict__ leafBox, float4* __restrict__ nodes)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -416,15 +953,30 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
     const DevScene& sc = scene->dev;
     const uint32_t leafBlocks = (uint32_t(n) + kBlock - 1) / kBlock;
 
+    // PT_BVH_BUILDER=morton selects the radix tree over Morton codes; the default is the surface-area builder
+    const char* which = std::getenv("PT_BVH_BUILDER");
+    const bool morton = which && std::strcmp(which, "morton") == 0;
+    if (which && !morton && std::strcmp(which, "sah") != 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "PT_BVH_BUILDER must be sah or morton");
+
     // work area: one allocation, kept with the scene for the next frame
-    size_t sortBytes = 0;
-    uint64_t* nullKeys = nullptr;
-    uint32_t* nullVals = nullptr;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, nullKeys, nullKeys, nullVals, nullVals, size_t(n), 0, 63, stream));
     auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t need = pad(size_t(n) * 32) + pad(size_t(leafBlocks) * 32) + pad(64) + 2 * pad(size_t(n) * 8) + 2 * pad(size_t(n) * 4)
-        + 2 * pad(size_t(n) * 8) + pad(size_t(2 * n) * 4) + pad(size_t(n) * 32) + pad(size_t(n) * 4) + pad(size_t(2 * n) * 4)
-        + pad(sortBytes) + 4096;
+    size_t sortBytes = 0, scanBytes = 0;
+    const uint32_t maxActive = uint32_t(n) / (kSmallNode + 1u) + 1u;
+    size_t need = pad(size_t(n) * 32) + pad(size_t(leafBlocks) * 32) + pad(64) + 4096;
+    if (morton) {
+        uint64_t* nullKeys = nullptr;
+        uint32_t* nullVals = nullptr;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, nullKeys, nullKeys, nullVals, nullVals, size_t(n), 0, 63, stream));
+        need += 2 * pad(size_t(n) * 8) + 2 * pad(size_t(n) * 4) + 2 * pad(size_t(n) * 8) + pad(size_t(2 * n) * 4) + pad(size_t(n) * 32)
+            + pad(size_t(n) * 4) + pad(size_t(2 * n) * 4) + pad(sortBytes);
+    } else {
+        uint32_t* nullVals = nullptr;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scanBytes, nullVals, nullVals, 0u, size_t(n), rocprim::plus<uint32_t>(), stream));
+        need += 6 * pad(size_t(n) * 4) + 2 * pad(size_t(maxActive) * sizeof(ActiveNode)) + pad(size_t(maxActive) * sizeof(SplitRec))
+            + pad(size_t(maxActive) * kNodeBinWords * 4) + pad(size_t(n) * sizeof(SmallTask)) + pad(256) + pad(size_t(2 * n) * 4)
+            + pad(scanBytes);
+    }
     if (scene->buildCapacity < need) {
         if (scene->buildArea)
             HIP_TRY(hipFree(scene->buildArea));
@@ -437,19 +989,8 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
     float4* leafBox = carve<float4>(p, 2 * size_t(n));
     float4* blockBounds = carve<float4>(p, 2 * size_t(leafBlocks));
     float4* bounds = carve<float4>(p, 4);
-    uint64_t* codes = carve<uint64_t>(p, size_t(n));
-    uint64_t* codesSorted = carve<uint64_t>(p, size_t(n));
-    uint32_t* order = carve<uint32_t>(p, size_t(n));
-    uint32_t* orderSorted = carve<uint32_t>(p, size_t(n));
-    uint2* children = carve<uint2>(p, size_t(n));
-    uint2* range = carve<uint2>(p, size_t(n));
-    uint32_t* parent = carve<uint32_t>(p, 2 * size_t(n));
-    float4* innerBox = carve<float4>(p, 2 * size_t(n));
-    uint32_t* arrived = carve<uint32_t>(p, size_t(n));
-    uint32_t* place = carve<uint32_t>(p, 2 * size_t(n));
-    void* sortTemp = p;
 
-    hipLaunchKernelGGL(surfaceBoxesKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, sc, t0, t1, leafBox, blockBounds);
+    hipLaunchKernelGGL(surfaceBoxesKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, sc, t0, t1, leafBox, blockBounds, morton ? 0 : 1);
     if (n == 1) {
         hipLaunchKernelGGL(singleLeafKernel, dim3(1), dim3(64), 0, stream, leafBox, scene->nodes);
         HIP_TRY(hipGetLastError());
@@ -460,18 +1001,81 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         return PT_OK;
     }
     hipLaunchKernelGGL(reduceBoundsKernel, dim3(1), dim3(kBlock), 0, stream, blockBounds, leafBlocks, bounds);
-    hipLaunchKernelGGL(mortonKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, leafBox, bounds, uint32_t(n), codes, order);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(rocprim::radix_sort_pairs(sortTemp, sortBytes, codes, codesSorted, order, orderSorted, size_t(n), 0, 63, stream));
     const uint32_t innerBlocks = (uint32_t(n - 1) + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(hierarchyKernel, dim3(innerBlocks), dim3(kBlock), 0, stream, codesSorted, n, children, range, parent);
-    HIP_TRY(hipMemsetAsync(arrived, 0, size_t(n) * 4, stream));
-    hipLaunchKernelGGL(refitKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, leafBox, orderSorted, children, parent, n,
-                       reinterpret_cast<float*>(innerBox), arrived);
     const uint32_t allBlocks = (uint32_t(2 * n - 1) + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(layoutKernel, dim3(allBlocks), dim3(kBlock), 0, stream, leafBox, innerBox, orderSorted, children, range, parent,
-                       n, scene->nodes, place);
-    HIP_TRY(hipGetLastError());
+    // what the rows are made from afterwards
+    uint2 *children = nullptr, *range = nullptr;
+    uint32_t *orderSorted = nullptr, *place = nullptr, *firstLeaf = nullptr;
+    if (morton) {
+        uint64_t* codes = carve<uint64_t>(p, size_t(n));
+        uint64_t* codesSorted = carve<uint64_t>(p, size_t(n));
+        uint32_t* order = carve<uint32_t>(p, size_t(n));
+        orderSorted = carve<uint32_t>(p, size_t(n));
+        children = carve<uint2>(p, size_t(n));
+        range = carve<uint2>(p, size_t(n));
+        uint32_t* parent = carve<uint32_t>(p, 2 * size_t(n));
+        float4* innerBox = carve<float4>(p, 2 * size_t(n));
+        uint32_t* arrived = carve<uint32_t>(p, size_t(n));
+        place = carve<uint32_t>(p, 2 * size_t(n));
+        void* sortTemp = p;
+        hipLaunchKernelGGL(mortonKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, leafBox, bounds, uint32_t(n), codes, order);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(rocprim::radix_sort_pairs(sortTemp, sortBytes, codes, codesSorted, order, orderSorted, size_t(n), 0, 63, stream));
+        hipLaunchKernelGGL(hierarchyKernel, dim3(innerBlocks), dim3(kBlock), 0, stream, codesSorted, n, children, range, parent);
+        HIP_TRY(hipMemsetAsync(arrived, 0, size_t(n) * 4, stream));
+        hipLaunchKernelGGL(refitKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, leafBox, orderSorted, children, parent, n,
+                           reinterpret_cast<float*>(innerBox), arrived);
+        hipLaunchKernelGGL(layoutKernel, dim3(allBlocks), dim3(kBlock), 0, stream, leafBox, innerBox, orderSorted, children, range, parent,
+                           n, scene->nodes, place);
+        HIP_TRY(hipGetLastError());
+    } else {
+        uint32_t* idx[2] = { carve<uint32_t>(p, size_t(n)), carve<uint32_t>(p, size_t(n)) };
+        uint32_t* nodeAt[2] = { carve<uint32_t>(p, size_t(n)), carve<uint32_t>(p, size_t(n)) };
+        uint32_t* flags = carve<uint32_t>(p, size_t(n));
+        uint32_t* leftBefore = carve<uint32_t>(p, size_t(n));
+        ActiveNode* active[2] = { carve<ActiveNode>(p, maxActive), carve<ActiveNode>(p, maxActive) };
+        SplitRec* splits = carve<SplitRec>(p, maxActive);
+        uint32_t* bins = carve<uint32_t>(p, size_t(maxActive) * kNodeBinWords);
+        SmallTask* small = carve<SmallTask>(p, size_t(n));
+        uint32_t* counters = carve<uint32_t>(p, 64);
+        firstLeaf = carve<uint32_t>(p, 2 * size_t(n));
+        void* scanTemp = p;
+        HIP_TRY(hipMemsetAsync(counters, 0, 256, stream));
+        hipLaunchKernelGGL(sahStartKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, bounds, uint32_t(n), active[0], idx[0], nodeAt[0],
+                           small, counters);
+        HIP_TRY(hipGetLastError());
+        uint32_t nActive = uint32_t(n) > kSmallNode ? 1u : 0u, nSmall = nActive ? 0u : 1u;
+        int cur = 0;
+        for (int level = 0; nActive > 0; level++) {
+            if (nActive > maxActive)
+                return fail(PT_ERR_LIMIT, "surface-area builder: more live nodes than the work area holds");
+            const size_t binWords = size_t(nActive) * kNodeBinWords;
+            hipLaunchKernelGGL(clearBinsKernel, dim3(uint32_t((binWords + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, bins, binWords);
+            hipLaunchKernelGGL(binKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, uint32_t(n), idx[cur], nodeAt[cur], active[cur], leafBox,
+                               bins);
+            HIP_TRY(hipMemsetAsync(counters, 0, 4, stream));
+            // a tree 48 levels deep over nodes of more than 64 surfaces is degenerate: halve from there on
+            hipLaunchKernelGGL(splitKernel, dim3(nActive), dim3(128), 0, stream, active[cur], bins, level >= 48 ? 1 : 0, splits,
+                               active[cur ^ 1], small, counters, scene->nodes, firstLeaf);
+            hipLaunchKernelGGL(flagKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, uint32_t(n), idx[cur], nodeAt[cur], active[cur], splits,
+                               leafBox, flags);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(rocprim::exclusive_scan(scanTemp, scanBytes, flags, leftBefore, 0u, size_t(n), rocprim::plus<uint32_t>(), stream));
+            hipLaunchKernelGGL(scatterKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, uint32_t(n), idx[cur], nodeAt[cur], active[cur],
+                               splits, flags, leftBefore, idx[cur ^ 1], nodeAt[cur ^ 1]);
+            HIP_TRY(hipGetLastError());
+            uint32_t h[2] = { 0, 0 };
+            HIP_TRY(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            nActive = h[0];
+            nSmall = h[1];
+            cur ^= 1;
+        }
+        if (nSmall > uint32_t(n))
+            return fail(PT_ERR_LIMIT, "surface-area builder: more subtrees than surfaces");
+        hipLaunchKernelGGL(smallSubtreesKernel, dim3(nSmall), dim3(64), 0, stream, small, idx[cur], leafBox, scene->nodes, firstLeaf);
+        HIP_TRY(hipGetLastError());
+    }
 
     // the grid of the rows spans the root box: the only values that cross to the host
     float root[8];
@@ -499,9 +1103,14 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         scene->dev.qstep[a] = st;
     }
     if (gridOk) {
-        hipLaunchKernelGGL(wideRowsKernel, dim3(innerBlocks), dim3(kBlock), 0, stream, sc, scene->nodes, children, range, place,
-                           orderSorted, n, v3(scene->dev.qbase[0], scene->dev.qbase[1], scene->dev.qbase[2]),
-                           v3(scene->dev.qstep[0], scene->dev.qstep[1], scene->dev.qstep[2]), scene->wide);
+        const V3 base = v3(scene->dev.qbase[0], scene->dev.qbase[1], scene->dev.qbase[2]);
+        const V3 step = v3(scene->dev.qstep[0], scene->dev.qstep[1], scene->dev.qstep[2]);
+        if (morton)
+            hipLaunchKernelGGL(wideRowsKernel, dim3(innerBlocks), dim3(kBlock), 0, stream, sc, scene->nodes, children, range, place,
+                               orderSorted, n, base, step, scene->wide);
+        else
+            hipLaunchKernelGGL(rowsFromNodesKernel, dim3(allBlocks), dim3(kBlock), 0, stream, sc, scene->nodes, firstLeaf,
+                               uint32_t(2 * n - 1), base, step, scene->wide);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(call.done(stream));

@@ -20,6 +20,14 @@ pytestmark = pytest.mark.gpu
 NO_HIT = 0xFFFFFFFF
 
 
+@pytest.fixture(params=["sah", "morton"], autouse=True)
+def builder(request):
+    """Every test runs with both device builders (PT_BVH_BUILDER; the surface-area builder is the default)."""
+    os.environ["PT_BVH_BUILDER"] = request.param
+    yield request.param
+    del os.environ["PT_BVH_BUILDER"]
+
+
 def check_tree(nodes, n_surfaces):
     """Pre-order layout, every surface in exactly one leaf, inner boxes = merge of the children's."""
     n = len(nodes)
@@ -86,6 +94,8 @@ def test_device_built_tree(name, in_memory, oracle):
             dev.build_bvh_device(p.t0, p.t1)
             nodes = dev.get_bvh()
             check_tree(nodes, len(s.surfaces))
+            dev.build_bvh_device(p.t0, p.t1)
+            assert dev.get_bvh().tobytes() == nodes.tobytes()  # equal inputs, equal trees
             # leaf boxes: the host builder's (static surfaces bit for bit; a moving surface's 16 poses go through
             # the C library's sin/cos there and the portable ones here, an ulp apart at most)
             lo, hi = leaf_boxes(nodes, len(s.surfaces))
@@ -114,6 +124,38 @@ def test_device_built_tree(name, in_memory, oracle):
         assert differ_hit <= 1e-4, differ_hit
         assert np.mean(got["a"][both] != want_ref["a"][both]) <= 1e-4
         assert np.mean(got["surface"][both] != want_ref["surface"][both]) <= 5e-3
+
+
+def tree_cost(nodes):
+    """Surface-area cost of a tree: box areas of all nodes relative to the root's."""
+    d = (nodes["hi"] - nodes["lo"]).astype(np.float64)
+    area = d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]
+    return float(area.sum() / area[0])
+
+
+def test_surface_area_builder_gives_the_cheaper_tree(builder):
+    """On the displaced grid (7 200 triangles: passes over large nodes and one-wave subtrees) the surface-area
+    builder's tree costs less than the radix tree over Morton codes and than the reference builder's."""
+    if builder != "sah":
+        pytest.skip("compares the two builders itself")
+    s, cam = scenes.big_mesh_scene(60)
+    host = tree_cost(s.nodes)
+    cost = {}
+    with pt.DeviceScene(s) as dev:
+        for which in ("sah", "morton"):
+            os.environ["PT_BVH_BUILDER"] = which
+            dev.build_bvh_device()
+            cost[which] = tree_cost(dev.get_bvh())
+    os.environ["PT_BVH_BUILDER"] = "sah"
+    assert cost["sah"] < 0.95 * cost["morton"] and cost["sah"] < host, (cost, host)
+
+
+def test_unknown_builder_is_refused():
+    s, cam, p = scenes.build("spheres")
+    with pt.DeviceScene(s) as dev:
+        os.environ["PT_BVH_BUILDER"] = "best"
+        with pytest.raises(pt.PtError):
+            dev.build_bvh_device()
 
 
 def test_scene_created_without_a_tree(oracle):
@@ -152,16 +194,17 @@ def test_single_surface_scene(oracle):
 
 
 def test_degenerate_inputs(oracle):
-    """Surfaces with identical boxes (equal Morton codes are told apart by position), a scene flat in one
-    axis, and two surfaces only."""
+    """Surfaces with identical boxes (equal Morton codes are told apart by position; no plane separates their
+    centres, so the surface-area builder halves them by place -- 300 of them exercise that in its passes over large
+    nodes, 37 in its one-wave subtrees), a scene flat in one axis, and two surfaces only."""
     cam = scenes.build("spheres")[1]
     q = pt.make_params(20, 14, 2, seed=4)
-    for variant in ("duplicates", "flat", "two"):
+    for variant in ("duplicates", "many duplicates", "flat", "two"):
         s = pt.FlatScene()
         light = s.material_light((6.0, 6.0, 6.0))
         grey = s.material_lambertian(s.texture_constant((0.6, 0.6, 0.6)))
-        if variant == "duplicates":
-            for _ in range(37):
+        if variant in ("duplicates", "many duplicates"):
+            for _ in range(37 if variant == "duplicates" else 300):
                 s.add_sphere((0.5, 0.0, 0.0), 0.8, grey)
             for _ in range(5):
                 s.add_sphere((-1.5, 1.0, 0.5), 0.4, light, is_light=True)

@@ -17,13 +17,15 @@ timeout -k 10 300 python3 bench.py --workload textured --steps 1 --warmup 1 > "$
 echo textured done
 timeout -k 10 300 python3 bench.py --workload frames --steps 1 --warmup 1 > "$OUT/${P}_bench_frames.json" 2> "$OUT/frames.err"
 echo frames done
-timeout -k 10 300 python3 bench.py --workload frames --bvh device --steps 1 --warmup 1 > "$OUT/${P}_bench_frames_devicebvh.json" 2> "$OUT/framesdev.err"
-echo frames device done
+timeout -k 10 300 python3 bench.py --workload frames --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_frames_hosttree.json" 2> "$OUT/frameshost.err"
+echo frames host tree done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mesh" -o mesh -- \
     python3 bench.py --workload mesh1000 --steps 1 --warmup 1 > "$OUT/${P}_bench_mesh1000.json" 2> "$OUT/mesh.err"
 echo mesh done
-timeout -k 10 300 python3 bench.py --workload mesh1000 --bvh device --steps 1 --warmup 1 > "$OUT/${P}_bench_mesh1000_devicebvh.json" 2> "$OUT/meshdev.err"
-echo mesh device done
+timeout -k 10 300 python3 bench.py --workload mesh1000 --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_mesh1000_hosttree.json" 2> "$OUT/meshhost.err"
+echo mesh host tree done
+timeout -k 10 300 python3 bench.py --workload cornell --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_cornell_hosttree.json" 2> "$OUT/cornellhost.err"
+echo cornell host tree done
 for WL in cornell mesh1000 textured frames; do
     bash tools/collect_traffic.sh $WL > "$OUT/traffic_$WL.out" 2>&1
     echo traffic $WL done
