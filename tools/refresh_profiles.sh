@@ -10,6 +10,12 @@ OUT=$ROOT/gpurun_out/refresh
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
+# the counter passes first: the benchmark lines below quote them from profiles/
+for WL in cornell mesh1000 textured frames; do
+    bash tools/collect_traffic.sh $WL > "$OUT/traffic_$WL.out" 2>&1
+    cp "$ROOT/gpurun_out/traffic_$WL.json" "$ROOT/profiles/traffic_$WL.json"
+    echo traffic $WL done
+done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/default" -o default -- \
     python3 bench.py > "$OUT/${P}_bench_default.json" 2> "$OUT/default.err"
 echo default done
@@ -26,7 +32,3 @@ timeout -k 10 300 python3 bench.py --workload mesh1000 --bvh host --steps 1 --wa
 echo mesh host tree done
 timeout -k 10 300 python3 bench.py --workload cornell --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_cornell_hosttree.json" 2> "$OUT/cornellhost.err"
 echo cornell host tree done
-for WL in cornell mesh1000 textured frames; do
-    bash tools/collect_traffic.sh $WL > "$OUT/traffic_$WL.out" 2>&1
-    echo traffic $WL done
-done
