@@ -142,6 +142,32 @@ PT_DEV V2 uniformInDisk(float u0, float u1)
     ptm::sincosf(theta, s, c);
     return V2{ c * r, s * r };
 }
+// uniformInDisk(u0, u1) * 0: what is left of the lens sample of a pinhole camera (aperture radius 0) is the sign
+// of each zero, or NaN where the disk sample is 0/0 -- decided without evaluating sine and cosine: in the first
+// branch |theta| <= pi/4, so the cosine is positive and the sine has theta's sign (sin(-0) = -0); in the second
+// theta lies in [pi/4, 3 pi/4], the sine is positive and the cosine is positive exactly for floats below
+// float(pi/2), which lies above pi/2 while its predecessor lies below.
+PT_DEV V2 uniformInDiskTimesZero(float u0, float u1, float zero)
+{
+    float ox = 2.0f * u0 - 1.0f;
+    float oy = 2.0f * u1 - 1.0f;
+    float theta, r, c, s;
+    if (fabs_(ox) > fabs_(oy)) {
+        r = ox;
+        theta = kPi / 4.0f * (oy / ox);
+        c = 1.0f;
+        s = __builtin_copysignf(1.0f, theta);
+    } else {
+        r = oy;
+        theta = 0.5f * kPi - kPi / 4.0f * (ox / oy);
+        c = theta < 0.5f * kPi ? 1.0f : -1.0f;
+        s = 1.0f;
+    }
+    if (theta != theta)
+        c = s = theta;
+    r = __builtin_copysignf(1.0f, r);
+    return V2{ c * r * zero, s * r * zero };
+}
 PT_DEV V3 cosineWeightedOnHemisphere(float u0, float u1)
 {
     V2 d = uniformInDisk(u0, u1);
@@ -1239,8 +1265,13 @@ __device__ inline Ray cameraRay(const pt_camera& cam, float p, float q, float t0
     P = P * cam.focus_distance;
     float second = rng.in01();
     float first = rng.in01();
-    V2 lens = uniformInDisk(first, second);
-    lens = V2{ lens.x * cam.aperture_radius, lens.y * cam.aperture_radius };
+    V2 lens;
+    if (cam.aperture_radius == 0.0f) {
+        lens = uniformInDiskTimesZero(first, second, cam.aperture_radius);
+    } else {
+        lens = uniformInDisk(first, second);
+        lens = V2{ lens.x * cam.aperture_radius, lens.y * cam.aperture_radius };
+    }
     V3 O = v3(lens.x, lens.y, 0.0f);
     V3 D = P - O;
     float t = mixf(t0, t1, rng.in01());
