@@ -513,6 +513,9 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
     float gate = 0.0f, cull = kFltMax, otherT = kFltMax;
     float dropGate = __builtin_huge_valf(); // nearest entry distance of a subtree that found no room on the stack
     HitLite best = noHit();
+    // shadow rays: the chosen light, and the distance below which any other surface settles the question
+    uint32_t lightSid = PT_NO_HIT;
+    float settledBelow = -__builtin_huge_valf();
 
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
@@ -537,13 +540,36 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                     ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
                     have = true;
                 }
+                float cullStart = kFltMax;
+#ifndef PT_NO_SHADOW_BOUND
+                if (shadow) {
+                    // All that is asked of this ray is whether its closest hit is the chosen light (reference
+                    // src/15/pathtracer.cpp:97-100).  The light's own test, the one the walk makes when it reaches
+                    // the light's leaf, says where: a miss means no walk can find it; a hit at aL means nothing
+                    // beyond aL can be the closest hit, and any other surface found well before aL ends the walk.
+                    lightSid = fbits(pool.sh_c[itemBase + item].w) & kLightMask;
+                    HitLite lh;
+                    if (STATS)
+                        nTests++;
+                    if (surfaceTest<DYN>(sc, surf, lightSid, ray, 0.0001f, kFltMax, lh)) {
+                        cullStart = lh.a * (1.0f + kTieBand);
+                        if (!(cullStart < kFltMax))
+                            cullStart = kFltMax;
+                        settledBelow = lh.a * (1.0f - kTieBand);
+                    } else {
+                        have = false;
+                        if (STATS)
+                            nRays++;
+                    }
+                }
+#endif
                 if (have) {
                     if (STATS) {
                         nRays++;
                         nRows++; // the root's box
                     }
                     best = noHit();
-                    cull = kFltMax;
+                    cull = cullStart;
                     otherT = kFltMax;
                     dropGate = __builtin_huge_valf();
                     top = 0;
@@ -671,6 +697,16 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
                 } else {
                     otherT = fminf(otherT, h.a);
                 }
+#ifndef PT_NO_SHADOW_BOUND
+                if (shadow && h.sid != lightSid && fmaxf(h.a, gate) < settledBelow) {
+                    // another surface, reached through boxes entered before the light is hit, and hit before it:
+                    // whatever the closest hit is, it is not the light
+                    best = noHit();
+                    otherT = kFltMax;
+                    dropGate = __builtin_huge_valf();
+                    top = 0;
+                }
+#endif
             }
             walkOver = true;
             while (top > 0) {
@@ -737,9 +773,14 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
     }
     flushRetries(pool, counters, waveIdx, retryBuf[threadIdx.x >> 6], nRetry);
     addStats<STATS>(stats, shadow ? kStatShadowRays : kStatPathRays, nRays);
+#ifdef PT_EXPERIMENT_SHADOW_ROWS
+    addStats<STATS>(stats, shadow ? kStatLeafRows : kStatBoxRows, nRows);
+    addStats<STATS>(stats, shadow ? kStatRetrySurfaceTests : kStatSurfaceTests, nTests);
+#else
     addStats<STATS>(stats, kStatBoxRows, nRows);
     addStats<STATS>(stats, kStatLeafRows, nLeafRows);
     addStats<STATS>(stats, kStatSurfaceTests, nTests);
+#endif
     addStats<STATS>(stats, kStatRetryRays, nAmbiguous);
 }
 
