@@ -462,17 +462,21 @@ PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx,
 #ifndef PT_ORDERED_WAVES
 #define PT_ORDERED_WAVES 6
 #endif
+#ifndef PT_ORDERED_BLOCK
+#define PT_ORDERED_BLOCK 256
+#endif
+constexpr uint32_t kOrderedBlock = PT_ORDERED_BLOCK; // threads per block of traceOrderedKernel
 template <bool DYN, bool STATS>
-__global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
+__global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                           float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
                                                           unsigned long long* __restrict__ stats)
 {
     uint32_t nRays = 0, nRows = 0, nLeafRows = 0, nTests = 0, nAmbiguous = 0;
-    __shared__ uint2 stack[kStackDepth][256];
-    __shared__ uint2 retryBuf[4][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
+    __shared__ uint2 stack[kStackDepth][kOrderedBlock];
+    __shared__ uint2 retryBuf[kOrderedBlock / 64u][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
     uint32_t nRetry = 0;                     // entries in this wave's part (the same in every lane)
     if (blockIdx.x == 0)
-        for (uint32_t q = threadIdx.x; q < kShards; q += 256u) {
+        for (uint32_t q = threadIdx.x; q < kShards; q += kOrderedBlock) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
             counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
             // the generateKernel before this launch gave path numbers to the places of region q that the
@@ -483,7 +487,7 @@ __global__ void __launch_bounds__(256, PT_ORDERED_WAVES) traceOrderedKernel(DevS
     const float4* __restrict__ nodes = sc.nodes;
     const uint4* __restrict__ wide = sc.wide;
     const float4* __restrict__ surf = sc.surf;
-    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
+    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * kOrderedBlock + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
     const bool shadow = waveIdx >= slotWaves;
@@ -1386,7 +1390,8 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
     unsigned long long* stats = STATS ? w.walkStats : nullptr;
     if (ordered) {
         sc->kt.begin(KernelTimes::kTraceOrdered, stream);
-        hipLaunchKernelGGL((traceOrderedKernel<DYN, STATS>), gridTrace, block, 0, stream, sc->dev, pool, w.counters, parity,
+        hipLaunchKernelGGL((traceOrderedKernel<DYN, STATS>), dim3((slotWaves + shadowWaves) / (kOrderedBlock / 64u)),
+                           dim3(kOrderedBlock), 0, stream, sc->dev, pool, w.counters, parity,
                            w.samples, shadowCap, slotWaves, stats);
         sc->kt.end(stream);
         // a multiple of kRetryShards blocks: a few per sub-list, more only for large pools
