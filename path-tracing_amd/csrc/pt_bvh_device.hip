@@ -411,7 +411,8 @@ struct ActiveNode {
     uint32_t pad2[2];
 };
 struct SplitRec {
-    uint32_t axis, plane, nLeft, pad;
+    uint32_t axis, plane, nLeft;
+    uint32_t swap; // the surfaces beyond the plane go to the first child
     uint32_t child[2]; // number of the child in the next pass's list, or kNone
     uint32_t pad2[2];
 };
@@ -601,6 +602,7 @@ __global__ void __launch_bounds__(128) splitKernel(const ActiveNode* __restrict_
     if (byPlace ? threadIdx.x != 0 : key != win)
         return;
     const ActiveNode nd = active[a];
+    SplitRec sp = {};
     uint32_t nLeft;
     if (byPlace) {
         // no plane separates the centres (or the tree is too deep already): halve the run of places; the halves
@@ -611,6 +613,17 @@ __global__ void __launch_bounds__(128) splitKernel(const ActiveNode* __restrict_
             addBin(L, nb + k * kBinWords);
         nLeft = nd.count / 2;
     } else {
+        // the half with more surfaces becomes the first child: the storage-order walk goes through the first
+        // child's subtree before it looks at the second, and the sooner it has a hit the more it can skip
+        // (measured on the scenes that are walked that way: tracing -1.5 % on the Cornell box, -4 % on the 100
+        // spheres; larger area first: +8 %, -4 %)
+        const bool swap = R.count > L.count;
+        if (swap) {
+            const BinBox t = L;
+            L = R;
+            R = t;
+        }
+        sp.swap = swap ? 1u : 0u;
         nLeft = L.count;
     }
     float lo[3], hi[3];
@@ -622,7 +635,6 @@ __global__ void __launch_bounds__(128) splitKernel(const ActiveNode* __restrict_
     nodes[2 * size_t(nd.place) + 0] = make_float4(lo[0], lo[1], lo[2], hi[0]);
     nodes[2 * size_t(nd.place) + 1] = make_float4(hi[1], hi[2], __uint_as_float(nd.place + 2u * nd.count - 1u), __uint_as_float(kInnerBit | second));
     firstLeaf[nd.place] = nd.begin;
-    SplitRec sp = {};
     sp.axis = byPlace ? kByPosition : axis;
     sp.plane = plane;
     sp.nLeft = nLeft;
@@ -672,7 +684,7 @@ __global__ void __launch_bounds__(kBlock) flagKernel(uint32_t n, const uint32_t*
             const float lo = sp.axis == 0 ? b0.x : (sp.axis == 1 ? b0.y : b0.z);
             const float hi = sp.axis == 0 ? b0.w : (sp.axis == 1 ? b1.x : b1.y);
             const ActiveNode& nd = active[a];
-            left = uint32_t(binOf(mixf(lo, hi, 0.5f), nd.lo[sp.axis], nd.hi[sp.axis])) < sp.plane ? 1u : 0u;
+            left = (uint32_t(binOf(mixf(lo, hi, 0.5f), nd.lo[sp.axis], nd.hi[sp.axis])) < sp.plane ? 1u : 0u) ^ sp.swap;
         }
     }
     flags[p] = left;
@@ -709,6 +721,7 @@ __global__ void __launch_bounds__(64) smallSubtreesKernel(const SmallTask* __res
                                                           const float4* __restrict__ leafBox, float4* __restrict__ nodes,
                                                           uint32_t* __restrict__ firstLeaf)
 {
+    __shared__ uint32_t sSwap[64];           // per node: the winner's second half goes first
     __shared__ float sBox[64][8];           // lo xyz, hi xyz, surface
     __shared__ unsigned long long sBest[64]; // per node (by its first lane): cheapest candidate
     __shared__ float sHalves[64][12];        // per node: boxes of the winner's two halves
@@ -823,15 +836,27 @@ __global__ void __launch_bounds__(64) smallSubtreesKernel(const SmallTask* __res
                 const float cm = wa == 0 ? c[0] : (wa == 1 ? c[1] : c[2]);
                 left = cm < cw || (cm == cw && lane < wl);
                 if (lane == wl) {
+                    float h[12];
                     for (int d = 0; d < 3; d++) {
-                        sHalves[nb][d] = wa == 0 ? Llo[0][d] : (wa == 1 ? Llo[1][d] : Llo[2][d]);
-                        sHalves[nb][3 + d] = wa == 0 ? Lhi[0][d] : (wa == 1 ? Lhi[1][d] : Lhi[2][d]);
-                        sHalves[nb][6 + d] = wa == 0 ? Rlo[0][d] : (wa == 1 ? Rlo[1][d] : Rlo[2][d]);
-                        sHalves[nb][9 + d] = wa == 0 ? Rhi[0][d] : (wa == 1 ? Rhi[1][d] : Rhi[2][d]);
+                        h[d] = wa == 0 ? Llo[0][d] : (wa == 1 ? Llo[1][d] : Llo[2][d]);
+                        h[3 + d] = wa == 0 ? Lhi[0][d] : (wa == 1 ? Lhi[1][d] : Lhi[2][d]);
+                        h[6 + d] = wa == 0 ? Rlo[0][d] : (wa == 1 ? Rlo[1][d] : Rlo[2][d]);
+                        h[9 + d] = wa == 0 ? Rhi[0][d] : (wa == 1 ? Rhi[1][d] : Rhi[2][d]);
+                    }
+                    // the half with more surfaces goes first (see splitKernel)
+                    const uint32_t cl = wa == 0 ? nL[0] : (wa == 1 ? nL[1] : nL[2]);
+                    const bool swap = nm - cl > cl;
+                    sSwap[nb] = swap ? 1u : 0u;
+                    for (int d = 0; d < 6; d++) {
+                        sHalves[nb][d] = swap ? h[6 + d] : h[d];
+                        sHalves[nb][6 + d] = swap ? h[d] : h[6 + d];
                     }
                 }
             }
         }
+        __syncthreads();
+        if (open && sBest[nb] != ~0ull && sSwap[nb])
+            left = !left;
         // stable partition inside each node: new lane of every surface
         const unsigned long long leftMask = __ballot(open && left);
         uint32_t to = lane;
