@@ -427,7 +427,7 @@ int pt_image_to_8bit(int device, const float* rgb, int width, int height, float 
  * same surface at the same distance except where two surfaces are hit at
  * exactly equal distances (the walk order decides those).  Equal inputs give
  * equal trees.  With PT_BVH_BUILDER=morton in the environment the tree is a
- * radix tree over Morton codes instead: a tenth of the build time, slower to
+ * radix tree over Morton codes instead: a fifth of the build time, slower to
  * walk.  A scene may be created with n_bvh_nodes == 0 and get its first tree
  * here.
  * pt_scene_get_bvh copies the installed tree out in the layout of

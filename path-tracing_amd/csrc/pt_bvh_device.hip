@@ -15,7 +15,7 @@
 // Two builders share that step and the tables they fill.  The default is the surface-area builder
 // (the reference's criterion, bvh.hpp:60-96, applied to 32 bins per axis for large nodes and to every
 // split of the sorted order for nodes of up to 64 surfaces; see "the surface-area builder" below).
-// PT_BVH_BUILDER=morton selects the radix tree, which is ten times quicker to build and up to half
+// PT_BVH_BUILDER=morton selects the radix tree, which is five times quicker to build and up to half
 // as fast to walk:
 //   mortonKernel        63-bit Morton code of each box centre inside the centre bounds
 //   rocprim radix sort  (code, surface) pairs
@@ -391,7 +391,8 @@ __global__ void __launch_bounds__(kBlock) wideRowsKernel(DevScene sc, const floa
 // surfaces at places [b, b + m) of the work order has its first child at P + 1 and, with mL surfaces in the first
 // child, its second child at P + 2 mL; its row of the `wide` table is P - b.
 //   nodes of more than 64 surfaces: per pass, every surface adds its box to one of 32 bins per axis of its node
-//     (binKernel; per-block bins in LDS where a block lies inside one node), the node picks the plane between bins
+//     (binNodesKernel, one wave per node of up to 2048 surfaces with its bins in LDS; binPlacesKernel for larger
+//     nodes, many blocks per node, per-block bins in LDS), the node picks the plane between bins
 //     with the smallest  area(left) * count(left) + area(right) * count(right)  (splitKernel), and a stable
 //     partition by a prefix sum over the whole order moves the surfaces (flagKernel, scan, scatterKernel);
 //   nodes of up to 64 surfaces: one wave each (smallSubtreesKernel) builds the whole subtree in LDS, trying every
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(kBlock) sahStartKernel(const float4* __restric
     if (p == 0 && n <= kSmallNode) {
         const SmallTask t = { 0u, 0u, n, 0u };
         small[0] = t;
-        counters[1] = 1u;
+        counters[2] = 1u;
     } else if (p == 0) {
         const float4 a = bounds[0], b = bounds[1];
         ActiveNode r = {};
@@ -494,53 +495,110 @@ PT_DEV void addToBins(uint32_t* bins, const ActiveNode& nd, float4 b0, float4 b1
     }
 }
 
-__global__ void __launch_bounds__(kBlock) binKernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ nodeAt,
-                                                    const ActiveNode* __restrict__ active, const float4* __restrict__ leafBox,
-                                                    uint32_t* __restrict__ bins)
+// Nodes of more than kWaveNodeMax surfaces are binned by place (binPlacesKernel: many blocks per node), the others
+// by one wave per node (binNodesKernel: no global atomics at all).
+constexpr uint32_t kWaveNodeMax = 2048;
+constexpr uint32_t kBinChunks = 8; // runs of kBlock places per block of binPlacesKernel
+
+PT_DEV void initBins(uint32_t* sBins, uint32_t thread, uint32_t threads)
+{
+    for (uint32_t i = thread; i < uint32_t(kNodeBinWords); i += threads) {
+        const uint32_t w = i % kBinWords;
+        sBins[i] = w == 0 ? 0u : (w <= 3 ? 0xFFFFFFFFu : 0u);
+    }
+}
+
+PT_DEV void flushBins(const uint32_t* sBins, uint32_t* __restrict__ g)
+{
+    for (uint32_t i = threadIdx.x; i < uint32_t(kNodeBinWords); i += kBlock) {
+        const uint32_t w = i % kBinWords, v = sBins[i];
+        if (w == 0) {
+            if (v)
+                atomicAdd(g + i, v);
+        } else if (w <= 3) {
+            if (v != 0xFFFFFFFFu)
+                atomicMin(g + i, v);
+        } else if (v) {
+            atomicMax(g + i, v);
+        }
+    }
+}
+
+// A block takes kBinChunks runs of kBlock places.  A node owns a run of places: the same node at both ends of a
+// run means the run lies inside it, and its surfaces go to bins in LDS that are added to the node's bins in memory
+// when the block moves on to another node or ends; the few runs that straddle nodes add to memory directly.
+__global__ void __launch_bounds__(kBlock) binPlacesKernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ nodeAt,
+                                                          const ActiveNode* __restrict__ active, const float4* __restrict__ leafBox,
+                                                          uint32_t* __restrict__ bins)
 {
     __shared__ uint32_t sBins[kNodeBinWords];
-    const uint32_t first = blockIdx.x * kBlock, last = min(first + kBlock, n) - 1u;
-    const uint32_t p = first + threadIdx.x;
-    // a node owns a run of places: the same live node at both ends of the block means the block lies inside it
-    const uint32_t aFirst = nodeAt[first];
-    const bool inOneNode = aFirst != kNone && aFirst == nodeAt[last];
-    if (inOneNode) {
-        for (uint32_t i = threadIdx.x; i < uint32_t(kNodeBinWords); i += kBlock) {
-            const uint32_t w = i % kBinWords;
-            sBins[i] = w == 0 ? 0u : (w <= 3 ? 0xFFFFFFFFu : 0u);
+    uint32_t held = kNone; // the node whose bins are in LDS (the same in every thread)
+    for (uint32_t c = 0; c < kBinChunks; c++) {
+        const uint32_t first = (blockIdx.x * kBinChunks + c) * kBlock;
+        if (first >= n)
+            break;
+        const uint32_t last = min(first + kBlock, n) - 1u, p = first + threadIdx.x;
+        const uint32_t aFirst = nodeAt[first];
+        const bool inOneNode = aFirst != kNone && aFirst == nodeAt[last] && active[aFirst].count > kWaveNodeMax;
+        if (inOneNode) {
+            if (held != aFirst) {
+                __syncthreads();
+                if (held != kNone)
+                    flushBins(sBins, bins + size_t(held) * kNodeBinWords);
+                __syncthreads();
+                initBins(sBins, threadIdx.x, kBlock);
+                __syncthreads();
+                held = aFirst;
+            }
+            if (p < n) {
+                const uint32_t s = idx[p];
+                addToBins(sBins, active[aFirst], leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
+                          [](uint32_t* w) { atomicAdd(w, 1u); }, [](uint32_t* w, uint32_t v) { atomicMin(w, v); },
+                          [](uint32_t* w, uint32_t v) { atomicMax(w, v); });
+            }
+        } else if (p < n) {
+            const uint32_t a = nodeAt[p];
+            if (a != kNone && active[a].count > kWaveNodeMax) {
+                const uint32_t s = idx[p];
+                addToBins(bins + size_t(a) * kNodeBinWords, active[a], leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
+                          [](uint32_t* w) { atomicAdd(w, 1u); }, [](uint32_t* w, uint32_t v) { atomicMin(w, v); },
+                          [](uint32_t* w, uint32_t v) { atomicMax(w, v); });
+            }
         }
-        __syncthreads();
-        if (p < n) {
-            const uint32_t s = idx[p];
-            addToBins(sBins, active[aFirst], leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
+    }
+    __syncthreads();
+    if (held != kNone)
+        flushBins(sBins, bins + size_t(held) * kNodeBinWords);
+}
+
+// One wave per live node of up to kWaveNodeMax surfaces: bins in LDS, written to memory whole.
+__global__ void __launch_bounds__(kBlock) binNodesKernel(uint32_t nActive, const uint32_t* __restrict__ idx,
+                                                         const ActiveNode* __restrict__ active, const float4* __restrict__ leafBox,
+                                                         uint32_t* __restrict__ bins)
+{
+    __shared__ uint32_t sBins[kBlock / 64][kNodeBinWords];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t a = blockIdx.x * (kBlock / 64) + wave;
+    ActiveNode nd = {};
+    if (a < nActive)
+        nd = active[a];
+    const bool mine = a < nActive && nd.count <= kWaveNodeMax;
+    if (mine)
+        initBins(sBins[wave], lane, 64u);
+    __syncthreads();
+    if (mine)
+        for (uint32_t k = lane; k < nd.count; k += 64u) {
+            const uint32_t s = idx[nd.begin + k];
+            addToBins(sBins[wave], nd, leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
                       [](uint32_t* w) { atomicAdd(w, 1u); }, [](uint32_t* w, uint32_t v) { atomicMin(w, v); },
                       [](uint32_t* w, uint32_t v) { atomicMax(w, v); });
         }
-        __syncthreads();
-        uint32_t* g = bins + size_t(aFirst) * kNodeBinWords;
-        for (uint32_t i = threadIdx.x; i < uint32_t(kNodeBinWords); i += kBlock) {
-            const uint32_t w = i % kBinWords, v = sBins[i];
-            if (w == 0) {
-                if (v)
-                    atomicAdd(g + i, v);
-            } else if (w <= 3) {
-                if (v != 0xFFFFFFFFu)
-                    atomicMin(g + i, v);
-            } else if (v) {
-                atomicMax(g + i, v);
-            }
-        }
-        return;
+    __syncthreads();
+    if (mine) {
+        uint32_t* g = bins + size_t(a) * kNodeBinWords;
+        for (uint32_t i = lane; i < uint32_t(kNodeBinWords); i += 64u)
+            g[i] = sBins[wave][i];
     }
-    if (p >= n)
-        return;
-    const uint32_t a = nodeAt[p];
-    if (a == kNone)
-        return;
-    const uint32_t s = idx[p];
-    addToBins(bins + size_t(a) * kNodeBinWords, active[a], leafBox[2 * size_t(s)], leafBox[2 * size_t(s) + 1],
-              [](uint32_t* w) { atomicAdd(w, 1u); }, [](uint32_t* w, uint32_t v) { atomicMin(w, v); },
-              [](uint32_t* w, uint32_t v) { atomicMax(w, v); });
 }
 
 struct BinBox {
@@ -568,101 +626,139 @@ PT_DEV void addBin(BinBox& b, const uint32_t* __restrict__ w)
     }
 }
 
-// One block of 128 threads per live node; thread (axis, plane) prices the split between bins plane - 1 and plane.
-__global__ void __launch_bounds__(128) splitKernel(const ActiveNode* __restrict__ active, const uint32_t* __restrict__ bins,
+// A block of 128 threads takes kSplitNodes live nodes in turn; thread (axis, plane) prices the split between bins
+// plane - 1 and plane.  The children are collected in LDS and get their numbers in the lists of the next pass with
+// one reservation per block and list (an atomic on one address completes at about 90 per microsecond: one per node
+// was a third of a millisecond per pass at 30 000 nodes).
+constexpr uint32_t kSplitNodes = 8;
+__global__ void __launch_bounds__(128) splitKernel(const ActiveNode* __restrict__ active, uint32_t nActive,
+                                                   uint32_t perBlock /* nodes per block, at most kSplitNodes */, const uint32_t* __restrict__ bins,
                                                    int halveAll, SplitRec* __restrict__ splits, ActiveNode* __restrict__ nextActive,
-                                                   SmallTask* __restrict__ small, uint32_t* __restrict__ counters /* [0] next, [1] small */,
+                                                   SmallTask* __restrict__ small,
+                                                   uint32_t* __restrict__ counters /* [0] live nodes of the next pass, [1] the largest of them, [2] small */,
                                                    float4* __restrict__ nodes, uint32_t* __restrict__ firstLeaf)
 {
-    __shared__ unsigned long long best;
-    const uint32_t a = blockIdx.x;
+    __shared__ unsigned long long best[kSplitNodes];
+    __shared__ ActiveNode sChild[2 * kSplitNodes]; // count 0: no such child
+    __shared__ uint32_t sBase[2];
     const uint32_t axis = threadIdx.x / kBins, plane = threadIdx.x % kBins;
-    const uint32_t* nb = bins + size_t(a) * kNodeBinWords;
-    if (threadIdx.x == 0)
-        best = ~0ull;
+    if (threadIdx.x < kSplitNodes)
+        best[threadIdx.x] = ~0ull;
+    if (threadIdx.x < 2 * kSplitNodes)
+        sChild[threadIdx.x].count = 0;
     __syncthreads();
-    BinBox L, R;
-    clearBox(L);
-    clearBox(R);
-    unsigned long long key = ~0ull;
-    if (axis < 3 && plane > 0 && !halveAll) {
-        for (uint32_t k = 0; k < uint32_t(kBins); k++)
-            addBin(k < plane ? L : R, nb + (axis * kBins + k) * kBinWords);
-        if (L.count > 0 && R.count > 0) {
-            const float cost = halfArea(L.lo, L.hi) * float(L.count) + halfArea(R.lo, R.hi) * float(R.count);
-            if (cost >= 0.0f && cost < __builtin_huge_valf())
-                key = ((unsigned long long) fbits(cost) << 32) | (axis << 8) | plane;
-        }
-    }
-    if (key != ~0ull)
-        atomicMin(&best, key);
-    __syncthreads();
-    const unsigned long long win = best;
-    const bool byPlace = win == ~0ull;
-    if (byPlace ? threadIdx.x != 0 : key != win)
-        return;
-    const ActiveNode nd = active[a];
-    SplitRec sp = {};
-    uint32_t nLeft;
-    if (byPlace) {
-        // no plane separates the centres (or the tree is too deep already): halve the run of places; the halves
-        // take this node's span for their bins, and their boxes come out of their own bins in the next pass
+    for (uint32_t g = 0; g < perBlock; g++) {
+        const uint32_t a = blockIdx.x * perBlock + g;
+        if (a >= nActive)
+            break;
+        const uint32_t* nb = bins + size_t(a) * kNodeBinWords;
+        BinBox L, R;
         clearBox(L);
         clearBox(R);
-        for (uint32_t k = 0; k < uint32_t(kBins); k++)
-            addBin(L, nb + k * kBinWords);
-        nLeft = nd.count / 2;
-    } else {
-        // the half with more surfaces becomes the first child: the storage-order walk goes through the first
-        // child's subtree before it looks at the second, and the sooner it has a hit the more it can skip
-        // (measured on the scenes that are walked that way: tracing -1.5 % on the Cornell box, -4 % on the 100
-        // spheres; larger area first: +8 %, -4 %)
-        const bool swap = R.count > L.count;
-        if (swap) {
-            const BinBox t = L;
-            L = R;
-            R = t;
+        unsigned long long key = ~0ull;
+        if (axis < 3 && plane > 0 && !halveAll) {
+            for (uint32_t k = 0; k < uint32_t(kBins); k++)
+                addBin(k < plane ? L : R, nb + (axis * kBins + k) * kBinWords);
+            if (L.count > 0 && R.count > 0) {
+                const float cost = halfArea(L.lo, L.hi) * float(L.count) + halfArea(R.lo, R.hi) * float(R.count);
+                if (cost >= 0.0f && cost < __builtin_huge_valf())
+                    key = ((unsigned long long) fbits(cost) << 32) | (axis << 8) | plane;
+            }
         }
-        sp.swap = swap ? 1u : 0u;
-        nLeft = L.count;
-    }
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; k++) {
-        lo[k] = fminf(L.lo[k], R.lo[k]);
-        hi[k] = fmaxf(L.hi[k], R.hi[k]);
-    }
-    const uint32_t second = nd.place + 2u * nLeft;
-    nodes[2 * size_t(nd.place) + 0] = make_float4(lo[0], lo[1], lo[2], hi[0]);
-    nodes[2 * size_t(nd.place) + 1] = make_float4(hi[1], hi[2], __uint_as_float(nd.place + 2u * nd.count - 1u), __uint_as_float(kInnerBit | second));
-    firstLeaf[nd.place] = nd.begin;
-    sp.axis = byPlace ? kByPosition : axis;
-    sp.plane = plane;
-    sp.nLeft = nLeft;
-    for (int c = 0; c < 2; c++) {
-        const uint32_t count = c == 0 ? nLeft : nd.count - nLeft;
-        const uint32_t place = c == 0 ? nd.place + 1u : second;
-        const uint32_t begin = c == 0 ? nd.begin : nd.begin + nLeft;
-        if (count > kSmallNode) {
-            const uint32_t slot = atomicAdd(&counters[0], 1u);
+        if (key != ~0ull)
+            atomicMin(&best[g], key);
+        __syncthreads();
+        const unsigned long long win = best[g];
+        const bool byPlace = win == ~0ull;
+        if (byPlace ? threadIdx.x != 0 : key != win)
+            continue;
+        const ActiveNode nd = active[a];
+        SplitRec sp = {};
+        uint32_t nLeft;
+        if (byPlace) {
+            // no plane separates the centres (or the tree is too deep already): halve the run of places; the halves
+            // take this node's span for their bins, and their boxes come out of their own bins in the next pass
+            clearBox(L);
+            clearBox(R);
+            for (uint32_t k = 0; k < uint32_t(kBins); k++)
+                addBin(L, nb + k * kBinWords);
+            nLeft = nd.count / 2;
+        } else {
+            // the half with more surfaces becomes the first child: the storage-order walk goes through the first
+            // child's subtree before it looks at the second, and the sooner it has a hit the more it can skip
+            // (measured on the scenes that are walked that way: tracing -1.5 % on the Cornell box, -4 % on the 100
+            // spheres; larger area first: +8 %, -4 %)
+            const bool swap = R.count > L.count;
+            if (swap) {
+                const BinBox t = L;
+                L = R;
+                R = t;
+            }
+            sp.swap = swap ? 1u : 0u;
+            nLeft = L.count;
+        }
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fminf(L.lo[k], R.lo[k]);
+            hi[k] = fmaxf(L.hi[k], R.hi[k]);
+        }
+        const uint32_t second = nd.place + 2u * nLeft;
+        nodes[2 * size_t(nd.place) + 0] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        nodes[2 * size_t(nd.place) + 1] = make_float4(hi[1], hi[2], __uint_as_float(nd.place + 2u * nd.count - 1u), __uint_as_float(kInnerBit | second));
+        firstLeaf[nd.place] = nd.begin;
+        sp.axis = byPlace ? kByPosition : axis;
+        sp.plane = plane;
+        sp.nLeft = nLeft;
+        sp.child[0] = sp.child[1] = kNone; // the live ones get their numbers below
+        splits[a] = sp;
+        for (int c = 0; c < 2; c++) {
             ActiveNode ch = {};
-            ch.place = place;
-            ch.begin = begin;
-            ch.count = count;
+            ch.place = c == 0 ? nd.place + 1u : second;
+            ch.begin = c == 0 ? nd.begin : nd.begin + nLeft;
+            ch.count = c == 0 ? nLeft : nd.count - nLeft;
             const BinBox& bx = c == 0 ? L : R;
             for (int k = 0; k < 3; k++) {
                 ch.lo[k] = byPlace ? nd.lo[k] : bx.lo[k];
                 ch.hi[k] = byPlace ? nd.hi[k] : bx.hi[k];
             }
-            nextActive[slot] = ch;
-            sp.child[c] = slot;
-        } else {
-            const uint32_t slot = atomicAdd(&counters[1], 1u);
-            SmallTask t = { place, begin, count, 0u };
-            small[slot] = t;
-            sp.child[c] = kNone;
+            sChild[2 * g + c] = ch;
         }
     }
-    splits[a] = sp;
+    __syncthreads();
+    // numbers for the children: one thread counts, one reservation per list
+    if (threadIdx.x == 0) {
+        uint32_t live = 0, little = 0, largest = 0;
+        for (uint32_t k = 0; k < 2 * kSplitNodes; k++) {
+            const uint32_t c = sChild[k].count;
+            live += c > kSmallNode ? 1u : 0u;
+            little += c > 0 && c <= kSmallNode ? 1u : 0u;
+            largest = max(largest, c);
+        }
+        sBase[0] = live ? atomicAdd(&counters[0], live) : 0u;
+        sBase[1] = little ? atomicAdd(&counters[2], little) : 0u;
+        if (live)
+            atomicMax(&counters[1], largest);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kSplitNodes) {
+        const ActiveNode ch = sChild[threadIdx.x];
+        if (ch.count > 0) {
+            uint32_t before = 0; // children of the same kind before this one
+            const bool live = ch.count > kSmallNode;
+            for (uint32_t k = 0; k < threadIdx.x; k++) {
+                const uint32_t c = sChild[k].count;
+                before += (live ? c > kSmallNode : (c > 0 && c <= kSmallNode)) ? 1u : 0u;
+            }
+            if (live) {
+                const uint32_t slot = sBase[0] + before;
+                nextActive[slot] = ch;
+                splits[blockIdx.x * perBlock + threadIdx.x / 2].child[threadIdx.x % 2] = slot;
+            } else {
+                const SmallTask t = { ch.place, ch.begin, ch.count, 0u };
+                small[sBase[1] + before] = t;
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) flagKernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ nodeAt,
@@ -1069,18 +1165,24 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         hipLaunchKernelGGL(sahStartKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, bounds, uint32_t(n), active[0], idx[0], nodeAt[0],
                            small, counters);
         HIP_TRY(hipGetLastError());
-        uint32_t nActive = uint32_t(n) > kSmallNode ? 1u : 0u, nSmall = nActive ? 0u : 1u;
+        uint32_t nActive = uint32_t(n) > kSmallNode ? 1u : 0u, nSmall = nActive ? 0u : 1u, largest = uint32_t(n);
         int cur = 0;
         for (int level = 0; nActive > 0; level++) {
             if (nActive > maxActive)
                 return fail(PT_ERR_LIMIT, "surface-area builder: more live nodes than the work area holds");
             const size_t binWords = size_t(nActive) * kNodeBinWords;
             hipLaunchKernelGGL(clearBinsKernel, dim3(uint32_t((binWords + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, bins, binWords);
-            hipLaunchKernelGGL(binKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, uint32_t(n), idx[cur], nodeAt[cur], active[cur], leafBox,
-                               bins);
-            HIP_TRY(hipMemsetAsync(counters, 0, 4, stream));
+            if (largest > kWaveNodeMax)
+                hipLaunchKernelGGL(binPlacesKernel, dim3((leafBlocks + kBinChunks - 1) / kBinChunks), dim3(kBlock), 0, stream, uint32_t(n),
+                                   idx[cur], nodeAt[cur], active[cur], leafBox, bins);
+            hipLaunchKernelGGL(binNodesKernel, dim3((nActive + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, stream, nActive, idx[cur],
+                               active[cur], leafBox, bins);
+            HIP_TRY(hipMemsetAsync(counters, 0, 8, stream));
             // a tree 48 levels deep over nodes of more than 64 surfaces is degenerate: halve from there on
-            hipLaunchKernelGGL(splitKernel, dim3(nActive), dim3(128), 0, stream, active[cur], bins, level >= 48 ? 1 : 0, splits,
+            // (few nodes: a block each, for the latency; many: several per block, for fewer reservations)
+            const uint32_t perBlock = nActive >= 2048u ? kSplitNodes : 1u;
+            hipLaunchKernelGGL(splitKernel, dim3((nActive + perBlock - 1) / perBlock), dim3(128), 0, stream, active[cur], nActive, perBlock,
+                               bins, level >= 48 ? 1 : 0, splits,
                                active[cur ^ 1], small, counters, scene->nodes, firstLeaf);
             hipLaunchKernelGGL(flagKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, uint32_t(n), idx[cur], nodeAt[cur], active[cur], splits,
                                leafBox, flags);
@@ -1089,11 +1191,12 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
             hipLaunchKernelGGL(scatterKernel, dim3(leafBlocks), dim3(kBlock), 0, stream, uint32_t(n), idx[cur], nodeAt[cur], active[cur],
                                splits, flags, leftBefore, idx[cur ^ 1], nodeAt[cur ^ 1]);
             HIP_TRY(hipGetLastError());
-            uint32_t h[2] = { 0, 0 };
+            uint32_t h[3] = { 0, 0, 0 };
             HIP_TRY(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             nActive = h[0];
-            nSmall = h[1];
+            largest = h[1];
+            nSmall = h[2];
             cur ^= 1;
         }
         if (nSmall > uint32_t(n))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time of building the acceleration structure: the host builder that restates the reference's
-(pt_bvh_build, one thread) against pt_scene_build_bvh_device, on the displaced-grid mesh.
+(pt_bvh_build, one thread) against pt_scene_build_bvh_device with both of its builders, on the displaced-grid mesh.
 usage: tools/bench_bvh_build.py [N ...]   (N x N cells, 2 N^2 + 2 triangles)"""
 import os
 import sys
@@ -19,12 +19,17 @@ for n in [int(a) for a in sys.argv[1:]] or [150, 500, 1000]:
     t = time.perf_counter()
     s.build_bvh()
     t_host = time.perf_counter() - t
+    best = {}
     with pt.DeviceScene(s) as dev:
-        dev.build_bvh_device()
-        times = []
-        for _ in range(5):
-            t = time.perf_counter()
-            dev.build_bvh_device()  # returns after the stream has drained
-            times.append(time.perf_counter() - t)
-    print("%8d surfaces: host builder %.3f s, device builder %.2f ms (best of 5; %.0fx)"
-          % (len(s.surfaces), t_host, min(times) * 1e3, t_host / min(times)), flush=True)
+        for which in ("sah", "morton"):
+            os.environ["PT_BVH_BUILDER"] = which
+            dev.build_bvh_device()
+            times = []
+            for _ in range(5):
+                t = time.perf_counter()
+                dev.build_bvh_device()  # returns after the stream has drained
+                times.append(time.perf_counter() - t)
+            best[which] = min(times)
+    del os.environ["PT_BVH_BUILDER"]
+    print("%8d surfaces: host builder %.3f s, device: surface-area builder %.2f ms (%.0fx), Morton radix tree %.2f ms (best of 5)"
+          % (len(s.surfaces), t_host, best["sah"] * 1e3, t_host / best["sah"], best["morton"] * 1e3), flush=True)
