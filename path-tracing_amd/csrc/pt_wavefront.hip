@@ -87,8 +87,8 @@ struct Batch {
 //                 blockIdx % S == q, their lists, and region q of a pool)
 //   S+1..3S       fill of the shadow-ray queue of shard q, double buffered by iteration parity
 //   3S+1..3S+64   rays the nearer-child-first tracing left for the storage-order pass, per sub-list
-//   then S each   entries of the hit list, of the miss list, and paths written to region q of the
-//                 other pool in this iteration
+//   then S each   entries of the hit list, paths written to region q of the other pool in this
+//                 iteration, and records in use at the front of region q of the pool traced next
 // Shards keep the returning atomics of one launch off a common address: one address serves
 // only about 90 of them per microsecond.  (Measured: one atomic per block on 8 shards beats one
 // per wave on 16..256 shards, which also fragments the shadow-ray queues.)
@@ -102,7 +102,8 @@ constexpr uint32_t kRetryShards = 64;            // sub-lists of the retry list 
 constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entries in the retry sub-lists
 constexpr uint32_t kCtrHit = kCtrRetry + kRetryShards; // .. + S - 1: entries in the hit list of shard q
 constexpr uint32_t kCtrLive = kCtrHit + kShards;        // .. + S - 1: continuing paths written to region q of the next pool
-constexpr uint32_t kCtrWords = (kCtrLive + kShards) * kCtrStride;
+constexpr uint32_t kCtrOcc = kCtrLive + kShards;         // .. + S - 1: records in use at the front of region q of the pool traced next
+constexpr uint32_t kCtrWords = (kCtrOcc + kShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
@@ -220,6 +221,18 @@ constexpr uint32_t kRefillLanesOrdered = PT_REFILL_LANES_ORDERED; // the same fo
 constexpr uint32_t kWalkLanesOrdered = PT_WALK_LANES_ORDERED;
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
+// The run of items of one wave inside a part (a region of a pool, a shard's shadow-ray queue) of `cap` items of which
+// the first `fill` are in use: 64 * kItemsPerLane consecutive ones -- or 64 when the part is at most 1 / kItemsPerLane
+// full, so that the few items at the front of a draining pool are spread over that many more waves (a wave works
+// its run off 64 at a time: with whole runs the last paths of a batch kept a few hundred waves busy for eight
+// rounds each while the rest of the chip had nothing to do).
+PT_DEV void waveRun(uint32_t waveInPart, uint32_t cap, uint32_t fill, uint32_t& pos, uint32_t& endPos)
+{
+    const uint32_t len = fill * kItemsPerLane <= cap ? 64u : 64u * kItemsPerLane;
+    pos = waveInPart * len;
+    endPos = min(pos + len, fill);
+}
+
 // Work of the walk a tracing kernel actually executes, summed per launch when STATS is on (an instrumented
 // build of the kernel, chosen at launch; the plain one carries none of this).  Index into the scene's block of
 // 64-bit sums:
@@ -289,18 +302,21 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     uint32_t pos, endPos;
     uint32_t itemBase = 0; // shadow waves: first entry of the wave's shard queue
     if (!shadow) {
-        pos = waveIdx * (64u * kItemsPerLane);
-        endPos = min(pos + 64u * kItemsPerLane, pool.nSlots);
+        // (a region is a whole number of runs)
+        const uint32_t regionCap = pool.nSlots / kShards, wavesPerRegion = regionCap / (64u * kItemsPerLane);
+        const uint32_t q = waveIdx / wavesPerRegion;
+        waveRun(waveIdx % wavesPerRegion, regionCap, counters[(kCtrOcc + q) * kCtrStride], pos, endPos);
+        pos += q * regionCap;
+        endPos += q * regionCap;
     } else {
         // the wave's run lies inside one shard queue (shadowCap is a multiple of the run length)
-        pos = (waveIdx - slotWaves) * (64u * kItemsPerLane);
-        const uint32_t shard = pos / shadowCap;
+        const uint32_t wavesPerQueue = shadowCap / (64u * kItemsPerLane);
+        const uint32_t shard = (waveIdx - slotWaves) / wavesPerQueue;
         if (shard >= kShards)
             return;
         const uint32_t fill = counters[(kCtrShadow + (parity ^ 1) * kShards + shard) * kCtrStride];
         itemBase = shard * shadowCap;
-        pos -= itemBase;
-        endPos = min(pos + 64u * kItemsPerLane, fill);
+        waveRun((waveIdx - slotWaves) % wavesPerQueue, shadowCap, fill, pos, endPos);
     }
     if (pos >= endPos)
         return;
@@ -494,17 +510,21 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
     uint32_t pos, endPos;
     uint32_t itemBase = 0;
     if (!shadow) {
-        pos = waveIdx * (64u * kItemsPerLane);
-        endPos = min(pos + 64u * kItemsPerLane, pool.nSlots);
+        // (a region is a whole number of runs)
+        const uint32_t regionCap = pool.nSlots / kShards, wavesPerRegion = regionCap / (64u * kItemsPerLane);
+        const uint32_t q = waveIdx / wavesPerRegion;
+        waveRun(waveIdx % wavesPerRegion, regionCap, counters[(kCtrOcc + q) * kCtrStride], pos, endPos);
+        pos += q * regionCap;
+        endPos += q * regionCap;
     } else {
-        pos = (waveIdx - slotWaves) * (64u * kItemsPerLane);
-        const uint32_t shard = pos / shadowCap;
+        // the wave's run lies inside one shard queue (shadowCap is a multiple of the run length)
+        const uint32_t wavesPerQueue = shadowCap / (64u * kItemsPerLane);
+        const uint32_t shard = (waveIdx - slotWaves) / wavesPerQueue;
         if (shard >= kShards)
             return;
         const uint32_t fill = counters[(kCtrShadow + (parity ^ 1) * kShards + shard) * kCtrStride];
         itemBase = shard * shadowCap;
-        pos -= itemBase;
-        endPos = min(pos + 64u * kItemsPerLane, fill);
+        waveRun((waveIdx - slotWaves) % wavesPerQueue, shadowCap, fill, pos, endPos);
     }
     if (pos >= endPos)
         return;
@@ -878,10 +898,17 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
     const uint32_t slot0 = blockIdx.x * kClassifyRecords + threadIdx.x; // the grid covers the records exactly
+    // only the records at the front of a region are in use (a region is a whole number of blocks); what lies behind
+    // them is whatever an earlier iteration left there
+    const uint32_t regionCap = pool.nSlots / kShards, region = blockIdx.x * kClassifyRecords / regionCap;
+    const uint32_t inUse = counters[(kCtrOcc + region) * kCtrStride];
+    const uint32_t inRegion0 = slot0 - region * regionCap;
+    if (inRegion0 - threadIdx.x >= inUse)
+        return;
     uint8_t cls[kClassifyChunks];
 #pragma unroll
     for (uint32_t j = 0; j < kClassifyChunks; j++)
-        cls[j] = pool.cls[slot0 + j * kClassifyBlock];
+        cls[j] = inRegion0 + j * kClassifyBlock < inUse ? pool.cls[slot0 + j * kClassifyBlock] : uint8_t(kClsEmpty);
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t wave = threadIdx.x >> 6, lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
@@ -1119,6 +1146,18 @@ __global__ void __launch_bounds__(256) generateKernel(DevScene sc, Pool next, Re
     const uint32_t shard = first / regionCap;
     const uint32_t goingOn = counters[(kCtrLive + shard) * kCtrStride];
     const uint32_t inRegion = first - shard * regionCap + threadIdx.x;
+    // records in use at the front of the region once this launch is through: the paths that go on and the new ones
+    // (shard q has the groups g = q, q + S, ... of 64 path numbers; see below).  The tracing and classifying kernels
+    // look at those only, so the places behind them are left as they are.
+    const uint32_t groups = b.totalIds >> 6;
+    const uint32_t mine = groups > shard ? (groups - shard + kShards - 1u) / kShards * 64u : 0u;
+    const uint32_t handedOut = counters[shard * kCtrStride];
+    const uint32_t left = mine > handedOut ? mine - handedOut : 0u;
+    const uint32_t inUse = goingOn + min(regionCap - goingOn, left);
+    if (inRegion == 0)
+        counters[(kCtrOcc + shard) * kCtrStride] = inUse;
+    if (inRegion >= inUse)
+        return;
     if (inRegion < goingOn)
         return; // a path that goes on
     // the free places of a region are one run, so their path numbers need no reservation; the next
@@ -1430,10 +1469,9 @@ void launchTraceFor(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStre
 int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch& b, const Pool pools[2], hipStream_t stream)
 {
     const uint32_t nSlots = pools[0].nSlots;
+    // (no paths yet: no records in use at the front of any region, so the first tracing and classifying launches
+    // look at nothing and the pools need no clearing)
     HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(pools[0].d_s, 0, size_t(nSlots) * 16, stream)); // no paths yet
-    HIP_TRY(hipMemsetAsync(pools[1].d_s, 0, size_t(nSlots) * 16, stream));
-    HIP_TRY(hipMemsetAsync(pools[0].cls, kClsEmpty, size_t(nSlots), stream));
     const uint64_t maxIters = (uint64_t(b.totalIds) / nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const bool dyn = sc->hasDynamic;
     const bool lds = sceneFitsLds(sc);
@@ -1593,10 +1631,13 @@ int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, co
     Pool pools[2];
     carvePools(w.pool, uint32_t(nSlots), pools);
     HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
-    // (no generateKernel ran: nothing to add to the path numbers, see runBatch)
-    for (uint32_t q = 0; q < kShards; q++)
+    // (no generateKernel ran: nothing to add to the path numbers, see runBatch; every record of the pool is in use)
+    for (uint32_t q = 0; q < kShards; q++) {
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrLive + q) * kCtrStride),
                                   int(nSlots / kShards), 1, stream));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrOcc + q) * kCtrStride),
+                                  int(nSlots / kShards), 1, stream));
+    }
     hipLaunchKernelGGL(fillRaysKernel, dim3(uint32_t(nSlots / 256u)), dim3(256), 0, stream, pools[0], n, d_origins, d_dirs,
                        d_times);
     launchTraceFor(scene, w, pools[0], stream, 0, scene->hasDynamic, sceneFitsLds(scene));
