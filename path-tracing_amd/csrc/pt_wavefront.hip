@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     // 64 entries a wave of shadeHitsKernel takes mostly run the same material code
     constexpr uint32_t kWaves = kClassifyBlock / 64;
     __shared__ uint32_t count[kHitClasses][kWaves]; // hits of class c in wave w; then their first place in the block's run
-    __shared__ uint32_t blockBase;
+    __shared__ uint32_t blockBase, present;
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
     const uint32_t slot0 = blockIdx.x * kClassifyRecords + threadIdx.x; // the grid covers the records exactly
@@ -912,12 +912,32 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     const uint32_t shard = blockIdx.x % kShards;
     const uint32_t wave = threadIdx.x >> 6, lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
+    // the classes that occur among the block's records (a scene has a few material types, not sixteen): the ranking
+    // below runs once per class that is there
+    if (threadIdx.x < kHitClasses * kWaves)
+        (&count[0][0])[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
+        present = 0;
+    __syncthreads();
+    {
+        uint32_t bits = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kClassifyChunks; j++)
+            if (cls[j] >= kClsHit)
+                bits |= 1u << min(uint32_t(cls[j] - kClsHit), kHitClasses - 1u);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            bits |= __shfl_xor(bits, off, 64);
+        if (lane == 0 && bits)
+            atomicOr(&present, bits);
+    }
+    __syncthreads();
     uint32_t rank[kClassifyChunks]; // among the wave's hits of the same class: run by run, lane by lane
 #pragma unroll
     for (uint32_t j = 0; j < kClassifyChunks; j++)
         rank[j] = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < kHitClasses; c++) {
+    for (uint32_t left = present; left != 0; left &= left - 1u) {
+        const uint32_t c = uint32_t(__ffs(int(left))) - 1u;
         uint32_t sofar = 0;
 #pragma unroll
         for (uint32_t j = 0; j < kClassifyChunks; j++) {
