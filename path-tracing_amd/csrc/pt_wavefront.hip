@@ -305,6 +305,8 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
         // (a region is a whole number of runs)
         const uint32_t regionCap = pool.nSlots / kShards, wavesPerRegion = regionCap / (64u * kItemsPerLane);
         const uint32_t q = waveIdx / wavesPerRegion;
+        if (q >= kShards)
+            return;
         waveRun(waveIdx % wavesPerRegion, regionCap, counters[(kCtrOcc + q) * kCtrStride], pos, endPos);
         pos += q * regionCap;
         endPos += q * regionCap;
@@ -513,6 +515,8 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
         // (a region is a whole number of runs)
         const uint32_t regionCap = pool.nSlots / kShards, wavesPerRegion = regionCap / (64u * kItemsPerLane);
         const uint32_t q = waveIdx / wavesPerRegion;
+        if (q >= kShards)
+            return;
         waveRun(waveIdx % wavesPerRegion, regionCap, counters[(kCtrOcc + q) * kCtrStride], pos, endPos);
         pos += q * regionCap;
         endPos += q * regionCap;
