@@ -616,6 +616,8 @@ try {
     // (the address of this GPU's copy of the fixed work area, for pt_render_device_noalloc: looked up here, at
     // set-up, so that the render call itself finds it in a table)
     if ((rc = ptWavefrontStaticSetup(device)) != PT_OK) return bail(rc);
+    if (hipDeviceGetAttribute(&sc->computeUnits, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || sc->computeUnits <= 0)
+        sc->computeUnits = 256;
     if (hipEventCreate(&sc->evStart) != hipSuccess || hipEventCreate(&sc->evStop) != hipSuccess
         || hipEventCreateWithFlags(&sc->evDone, hipEventDisableTiming) != hipSuccess) {
         pt_scene_destroy(sc);

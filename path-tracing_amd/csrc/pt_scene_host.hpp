@@ -142,6 +142,7 @@ struct KernelTimes {
 
 struct pt_scene {
     int device = 0;
+    int computeUnits = 0; // of that GPU: the tracing launches are sized to what it holds at once
     ptd::DevScene dev;
     std::vector<void*> owned; // every device allocation of the scene
     float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh

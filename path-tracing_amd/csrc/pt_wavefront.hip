@@ -103,7 +103,8 @@ constexpr uint32_t kCtrRetry = 3 * kShards + 1;  // .. + kRetryShards - 1: entri
 constexpr uint32_t kCtrHit = kCtrRetry + kRetryShards; // .. + S - 1: entries in the hit list of shard q
 constexpr uint32_t kCtrLive = kCtrHit + kShards;        // .. + S - 1: continuing paths written to region q of the next pool
 constexpr uint32_t kCtrOcc = kCtrLive + kShards;         // .. + S - 1: records in use at the front of region q of the pool traced next
-constexpr uint32_t kCtrWords = (kCtrOcc + kShards) * kCtrStride;
+constexpr uint32_t kCtrWork = kCtrOcc + kShards;        // .. + 2 S - 1: runs handed out of region q / of shadow queue q in this tracing launch
+constexpr uint32_t kCtrWords = (kCtrWork + 2 * kShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
@@ -221,16 +222,74 @@ constexpr uint32_t kRefillLanesOrdered = PT_REFILL_LANES_ORDERED; // the same fo
 constexpr uint32_t kWalkLanesOrdered = PT_WALK_LANES_ORDERED;
 constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while this many lanes do
 
-// The run of items of one wave inside a part (a region of a pool, a shard's shadow-ray queue) of `cap` items of which
-// the first `fill` are in use: 64 * kItemsPerLane consecutive ones -- or 64 when the part is at most 1 / kItemsPerLane
-// full, so that the few items at the front of a draining pool are spread over that many more waves (a wave works
-// its run off 64 at a time: with whole runs the last paths of a batch kept a few hundred waves busy for eight
-// rounds each while the rest of the chip had nothing to do).
-PT_DEV void waveRun(uint32_t waveInPart, uint32_t cap, uint32_t fill, uint32_t& pos, uint32_t& endPos)
+// A run of items inside a part (a region of a pool, a shard's shadow-ray queue) of `cap` items of which the first
+// `fill` are in use: 64 * kItemsPerLane consecutive ones -- or 64 when the part is at most 1 / kItemsPerLane full, so
+// that the few items at the front of a draining pool are spread over that many more waves (a wave works a run off
+// 64 at a time: with whole runs the last paths of a batch kept a few hundred waves busy for eight rounds each while
+// the rest of the chip had nothing to do).
+PT_DEV uint32_t runLength(uint32_t cap, uint32_t fill) { return fill * kItemsPerLane <= cap ? 64u : 64u * kItemsPerLane; }
+
+// Two ways of giving the waves of a tracing launch their runs.  Fixed: a wave per run, the launch covers all parts
+// (the hardware hands out blocks as others finish).  Taken: as many waves as the chip holds at once, which take run
+// after run from counters, one per region of the pool (kind 0) and one per shadow-ray queue (kind 1), cleared by
+// classifyKernel between two tracing launches: a wave that has worked off a run takes the next one and keeps its
+// lanes filled across the seam, so the thinning out at the end of a run happens once per wave and kind instead of
+// once per 512 rays.  Measured per kernel (see launchTrace): taken runs win where rays are long (scenes in memory,
+// moving surfaces: -5 to -10 %), fixed runs for the short walks of small static scenes (taken: +9 %).
+struct RunTaker {
+    uint32_t kind, part; // what the wave works on, and where it looks for its next run first
+};
+
+// items in use in each part: [kind * kShards + q]
+PT_DEV void fillsOfParts(const uint32_t* __restrict__ counters, int parity, uint32_t* sFill)
 {
-    const uint32_t len = fill * kItemsPerLane <= cap ? 64u : 64u * kItemsPerLane;
-    pos = waveInPart * len;
-    endPos = min(pos + len, fill);
+    if (threadIdx.x < 2u * kShards) {
+        const uint32_t q = threadIdx.x % kShards;
+        sFill[threadIdx.x] = threadIdx.x < kShards ? counters[(kCtrOcc + q) * kCtrStride]
+                                                   : counters[(kCtrShadow + uint32_t(parity ^ 1) * kShards + q) * kCtrStride];
+    }
+}
+
+// The next run of the wave's kind: from its part on, the first part with a run left; false when there is none.
+// (Everything here is the same in every lane.)
+PT_DEV bool takeRun(uint32_t* __restrict__ counters, const uint32_t* sFill, RunTaker& t, uint32_t regionCap, uint32_t shadowCap,
+                    uint32_t& pos, uint32_t& endPos)
+{
+    for (uint32_t tries = 0; tries < kShards; tries++, t.part = (t.part + 1u) % kShards) {
+        const uint32_t cap = t.kind == 0 ? regionCap : shadowCap;
+        const uint32_t fill = sFill[t.kind * kShards + t.part];
+        const uint32_t len = runLength(cap, fill);
+        const uint32_t runs = (fill + len - 1u) / len;
+        uint32_t* next = &counters[(kCtrWork + t.kind * kShards + t.part) * kCtrStride];
+        if (__hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= runs)
+            continue;
+        uint32_t r = 0;
+        if (laneId() == 0)
+            r = atomicAdd(next, 1u);
+        r = uint32_t(__builtin_amdgcn_readfirstlane(int(r)));
+        if (r < runs) {
+            // (items are numbered through the whole pool, or through all queues)
+            pos = t.part * cap + r * len;
+            endPos = t.part * cap + min(r * len + len, fill);
+            return true;
+        }
+    }
+    return false;
+}
+
+// The one run of wave `waveInKind` of a launch with fixed runs; false if its part has no such run.
+PT_DEV bool fixedRun(const uint32_t* sFill, uint32_t kind, uint32_t waveInKind, uint32_t regionCap, uint32_t shadowCap, uint32_t& pos,
+                     uint32_t& endPos)
+{
+    const uint32_t cap = kind == 0 ? regionCap : shadowCap;
+    const uint32_t wavesPerPart = cap / (64u * kItemsPerLane), part = waveInKind / wavesPerPart;
+    if (part >= kShards)
+        return false;
+    const uint32_t fill = sFill[kind * kShards + part], len = runLength(cap, fill);
+    const uint32_t first = (waveInKind % wavesPerPart) * len;
+    pos = part * cap + first;
+    endPos = part * cap + min(first + len, fill);
+    return first < fill;
 }
 
 // Work of the walk a tracing kernel actually executes, summed per launch when STATS is on (an instrumented
@@ -266,9 +325,9 @@ PT_DEV void addStats(unsigned long long* __restrict__ stats, uint32_t which, uin
 template <bool DYN, bool LDS, bool STATS>
 __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                    float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
-                                                   unsigned long long* __restrict__ stats)
+                                                   int taken, unsigned long long* __restrict__ stats)
 {
-    uint32_t nRays = 0, nRows = 0, nTests = 0;
+    uint32_t nRays = 0, nShadowRays = 0, nRows = 0, nTests = 0;
     // the queues this iteration's shadeKernel fills were read by the previous launch of this
     // kernel; this launch reads the other set
     if (blockIdx.x == 0)
@@ -283,8 +342,12 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
     // per-lane gathers of the walk off the vector memory path
     extern __shared__ float4 ldsGeo[];
+    __shared__ uint32_t sFill[2 * kShards];
+    fillsOfParts(counters, parity, sFill);
     const float4* nodes = sc.nodes;
     const float4* surf = sc.surf;
+    if (!LDS)
+        __syncthreads();
     if (LDS) {
         const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
         for (uint32_t i = threadIdx.x; i < nNode4; i += 256u)
@@ -298,30 +361,19 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
-    const bool shadow = waveIdx >= slotWaves; // the same for every lane of the wave
-    uint32_t pos, endPos;
-    uint32_t itemBase = 0; // shadow waves: first entry of the wave's shard queue
-    if (!shadow) {
-        // (a region is a whole number of runs)
-        const uint32_t regionCap = pool.nSlots / kShards, wavesPerRegion = regionCap / (64u * kItemsPerLane);
-        const uint32_t q = waveIdx / wavesPerRegion;
-        if (q >= kShards)
+    const uint32_t regionCap = pool.nSlots / kShards;
+    // 0: rays of paths (items are pool records), 1: shadow rays (items are queue entries); half of the waves begin
+    // with either kind and go over to the other when theirs is worked off and their lanes are empty (see takeRun)
+    // taken runs: half of the waves begin with either kind and go over to the other when theirs is worked off and
+    // their lanes are empty; fixed runs: the first slotWaves waves have the pool's regions, the others the queues
+    RunTaker taker = { taken ? (waveIdx / kShards) & 1u : (waveIdx >= slotWaves ? 1u : 0u), waveIdx % kShards };
+    bool kindDone = false, otherKindTried = false, allDone = false;
+    uint32_t pos = 0, endPos = 0; // the rest of the run in hand
+    if (!taken) {
+        kindDone = otherKindTried = allDone = true;
+        if (!fixedRun(sFill, taker.kind, taker.kind ? waveIdx - slotWaves : waveIdx, regionCap, shadowCap, pos, endPos))
             return;
-        waveRun(waveIdx % wavesPerRegion, regionCap, counters[(kCtrOcc + q) * kCtrStride], pos, endPos);
-        pos += q * regionCap;
-        endPos += q * regionCap;
-    } else {
-        // the wave's run lies inside one shard queue (shadowCap is a multiple of the run length)
-        const uint32_t wavesPerQueue = shadowCap / (64u * kItemsPerLane);
-        const uint32_t shard = (waveIdx - slotWaves) / wavesPerQueue;
-        if (shard >= kShards)
-            return;
-        const uint32_t fill = counters[(kCtrShadow + (parity ^ 1) * kShards + shard) * kCtrStride];
-        itemBase = shard * shadowCap;
-        waveRun((waveIdx - slotWaves) % wavesPerQueue, shadowCap, fill, pos, endPos);
     }
-    if (pos >= endPos)
-        return;
 
     bool have = false;
     uint32_t item = 0;
@@ -338,7 +390,21 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
         const uint32_t nIdle = uint32_t(__popcll(idle));
-        if (nIdle == 64u && pos >= endPos)
+        if (pos >= endPos && !allDone && nIdle >= kRefillLanes) {
+            if (!kindDone && !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos))
+                kindDone = true;
+            if (kindDone && nIdle == 64u) {
+                if (!otherKindTried) {
+                    otherKindTried = true;
+                    taker.kind ^= 1u;
+                    taker.part = waveIdx % kShards;
+                    kindDone = !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos);
+                }
+                allDone = kindDone;
+            }
+        }
+        const bool shadow = taker.kind != 0u; // the same for every lane of the wave, and for every ray it has under way
+        if (nIdle == 64u && pos >= endPos && allDone)
             break;
         if (pos < endPos && (nIdle >= kRefillLanes || nIdle == 64u)) {
             const uint32_t cand = pos + uint32_t(__popcll(idle & below));
@@ -352,8 +418,8 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
                         have = true;
                     }
                 } else {
-                    const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
-                    payload = pool.sh_c[itemBase + item];
+                    const float4 so = pool.sh_o[item], sd = pool.sh_d[item];
+                    payload = pool.sh_c[item];
                     dest = fbits(sd.w);
                     if (fbits(payload.w) & kDestIsSample) {
                         const float* p = samples + 3 * size_t(dest);
@@ -371,8 +437,10 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
                     cur = 0;
                     pending = kInner;
                     best = noHit();
-                    if (STATS)
-                        nRays++;
+                    if (STATS) {
+                        nRays += shadow ? 0u : 1u;
+                        nShadowRays += shadow ? 1u : 0u;
+                    }
                 }
             }
             pos = min(pos + nIdle, endPos);
@@ -413,11 +481,12 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
                                             fbits(best.a), fbits(best.u), fbits(best.v));
                 pool.cls[item] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
             } else {
-                shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
+                shadowArrive<DYN>(sc, surf, pool, samples, item, ray, best, payload, dest, destW, destValue);
             }
         }
     }
-    addStats<STATS>(stats, shadow ? kStatShadowRays : kStatPathRays, nRays);
+    addStats<STATS>(stats, kStatPathRays, nRays);
+    addStats<STATS>(stats, kStatShadowRays, nShadowRays);
     addStats<STATS>(stats, kStatBoxRows, nRows);
     addStats<STATS>(stats, kStatSurfaceTests, nTests);
 }
@@ -487,9 +556,9 @@ constexpr uint32_t kOrderedBlock = PT_ORDERED_BLOCK; // threads per block of tra
 template <bool DYN, bool STATS>
 __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                           float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
-                                                          unsigned long long* __restrict__ stats)
+                                                          int taken, unsigned long long* __restrict__ stats)
 {
-    uint32_t nRays = 0, nRows = 0, nLeafRows = 0, nTests = 0, nAmbiguous = 0;
+    uint32_t nRays = 0, nShadowRays = 0, nRows = 0, nLeafRows = 0, nTests = 0, nAmbiguous = 0;
     __shared__ uint2 stack[kStackDepth][kOrderedBlock];
     __shared__ uint2 retryBuf[kOrderedBlock / 64u][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
     uint32_t nRetry = 0;                     // entries in this wave's part (the same in every lane)
@@ -502,36 +571,28 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
             counters[q * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride];
             counters[(kCtrLive + q) * kCtrStride] = 0;
         }
+    __shared__ uint32_t sFill[2 * kShards];
+    fillsOfParts(counters, parity, sFill);
+    __syncthreads();
     const float4* __restrict__ nodes = sc.nodes;
     const uint4* __restrict__ wide = sc.wide;
     const float4* __restrict__ surf = sc.surf;
     const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * kOrderedBlock + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
-    const bool shadow = waveIdx >= slotWaves;
-    uint32_t pos, endPos;
-    uint32_t itemBase = 0;
-    if (!shadow) {
-        // (a region is a whole number of runs)
-        const uint32_t regionCap = pool.nSlots / kShards, wavesPerRegion = regionCap / (64u * kItemsPerLane);
-        const uint32_t q = waveIdx / wavesPerRegion;
-        if (q >= kShards)
+    const uint32_t regionCap = pool.nSlots / kShards;
+    // 0: rays of paths (items are pool records), 1: shadow rays (items are queue entries); half of the waves begin
+    // with either kind and go over to the other when theirs is worked off and their lanes are empty
+    // taken runs: half of the waves begin with either kind and go over to the other when theirs is worked off and
+    // their lanes are empty; fixed runs: the first slotWaves waves have the pool's regions, the others the queues
+    RunTaker taker = { taken ? (waveIdx / kShards) & 1u : (waveIdx >= slotWaves ? 1u : 0u), waveIdx % kShards };
+    bool kindDone = false, otherKindTried = false, allDone = false;
+    uint32_t pos = 0, endPos = 0;       // the rest of the run in hand
+    if (!taken) {
+        kindDone = otherKindTried = allDone = true;
+        if (!fixedRun(sFill, taker.kind, taker.kind ? waveIdx - slotWaves : waveIdx, regionCap, shadowCap, pos, endPos))
             return;
-        waveRun(waveIdx % wavesPerRegion, regionCap, counters[(kCtrOcc + q) * kCtrStride], pos, endPos);
-        pos += q * regionCap;
-        endPos += q * regionCap;
-    } else {
-        // the wave's run lies inside one shard queue (shadowCap is a multiple of the run length)
-        const uint32_t wavesPerQueue = shadowCap / (64u * kItemsPerLane);
-        const uint32_t shard = (waveIdx - slotWaves) / wavesPerQueue;
-        if (shard >= kShards)
-            return;
-        const uint32_t fill = counters[(kCtrShadow + (parity ^ 1) * kShards + shard) * kCtrStride];
-        itemBase = shard * shadowCap;
-        waveRun((waveIdx - slotWaves) % wavesPerQueue, shadowCap, fill, pos, endPos);
     }
-    if (pos >= endPos)
-        return;
 
     bool have = false;
     uint32_t item = 0;
@@ -548,7 +609,23 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
         const uint32_t nIdle = uint32_t(__popcll(idle));
-        if (nIdle == 64u && pos >= endPos)
+        if (pos >= endPos && !allDone && nIdle >= kRefillLanesOrdered) {
+            // the run is worked off: the next one of this kind; the other kind once this one is through and the
+            // lanes are empty (the two kinds end differently)
+            if (!kindDone && !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos))
+                kindDone = true;
+            if (kindDone && nIdle == 64u) {
+                if (!otherKindTried) {
+                    otherKindTried = true;
+                    taker.kind ^= 1u;
+                    taker.part = waveIdx % kShards;
+                    kindDone = !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos);
+                }
+                allDone = kindDone;
+            }
+        }
+        const bool shadow = taker.kind != 0u;
+        if (nIdle == 64u && pos >= endPos && allDone)
             break;
         if (pos < endPos && (nIdle >= kRefillLanesOrdered || nIdle == 64u)) {
             const uint32_t cand = pos + uint32_t(__popcll(idle & below));
@@ -564,7 +641,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                 } else {
                     // (what to add on arrival is read when the ray arrives: fewer registers held
                     // through the walk, more waves in flight)
-                    const float4 so = pool.sh_o[itemBase + item], sd = pool.sh_d[itemBase + item];
+                    const float4 so = pool.sh_o[item], sd = pool.sh_d[item];
                     ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
                     have = true;
                 }
@@ -575,7 +652,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     // src/15/pathtracer.cpp:97-100).  The light's own test, the one the walk makes when it reaches
                     // the light's leaf, says where: a miss means no walk can find it; a hit at aL means nothing
                     // beyond aL can be the closest hit, and any other surface found well before aL ends the walk.
-                    lightSid = fbits(pool.sh_c[itemBase + item].w) & kLightMask;
+                    lightSid = fbits(pool.sh_c[item].w) & kLightMask;
                     HitLite lh;
                     if (STATS)
                         nTests++;
@@ -587,13 +664,14 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     } else {
                         have = false;
                         if (STATS)
-                            nRays++;
+                            nShadowRays++;
                     }
                 }
 #endif
                 if (have) {
                     if (STATS) {
-                        nRays++;
+                        nRays += shadow ? 0u : 1u;
+                        nShadowRays += shadow ? 1u : 0u;
                         nRows++; // the root's box
                     }
                     best = noHit();
@@ -765,7 +843,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     if (!(bound < kFltMax))
                         bound = kFltMax;
                     retryBuf[threadIdx.x >> 6][nRetry + uint32_t(__popcll(am & below))]
-                        = make_uint2(shadow ? (kRetryIsShadow | (itemBase + item)) : item, fbits(bound));
+                        = make_uint2(shadow ? (kRetryIsShadow | (item)) : item, fbits(bound));
                 }
                 nRetry += uint32_t(__popcll(am));
                 if (STATS && ambiguous)
@@ -781,9 +859,9 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                                             fbits(best.a), fbits(best.u), fbits(best.v));
                 pool.cls[item] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
             } else if (best.sid != PT_NO_HIT) {
-                const float4 payload = pool.sh_c[itemBase + item];
+                const float4 payload = pool.sh_c[item];
                 if (best.sid == (fbits(payload.w) & kLightMask)) {
-                    const uint32_t dest = fbits(pool.sh_d[itemBase + item].w);
+                    const uint32_t dest = fbits(pool.sh_d[item].w);
                     V3 destValue;
                     uint32_t destW = 0;
                     if (fbits(payload.w) & kDestIsSample) {
@@ -794,21 +872,17 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                         destValue = v3(r.x, r.y, r.z);
                         destW = fbits(r.w);
                     }
-                    shadowArrive<DYN>(sc, surf, pool, samples, itemBase + item, ray, best, payload, dest, destW, destValue);
+                    shadowArrive<DYN>(sc, surf, pool, samples, item, ray, best, payload, dest, destW, destValue);
                 }
             }
         }
     }
     flushRetries(pool, counters, waveIdx, retryBuf[threadIdx.x >> 6], nRetry);
-    addStats<STATS>(stats, shadow ? kStatShadowRays : kStatPathRays, nRays);
-#ifdef PT_EXPERIMENT_SHADOW_ROWS
-    addStats<STATS>(stats, shadow ? kStatLeafRows : kStatBoxRows, nRows);
-    addStats<STATS>(stats, shadow ? kStatRetrySurfaceTests : kStatSurfaceTests, nTests);
-#else
+    addStats<STATS>(stats, kStatPathRays, nRays);
+    addStats<STATS>(stats, kStatShadowRays, nShadowRays);
     addStats<STATS>(stats, kStatBoxRows, nRows);
     addStats<STATS>(stats, kStatLeafRows, nLeafRows);
     addStats<STATS>(stats, kStatSurfaceTests, nTests);
-#endif
     addStats<STATS>(stats, kStatRetryRays, nAmbiguous);
 }
 
@@ -901,6 +975,8 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     __shared__ uint32_t blockBase, present;
     if (blockIdx.x == 0 && threadIdx.x < kRetryShards)
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
+    if (blockIdx.x == 0 && threadIdx.x < 2u * kShards)
+        counters[(kCtrWork + threadIdx.x) * kCtrStride] = 0; // the next tracing launch hands out its runs from the start
     const uint32_t slot0 = blockIdx.x * kClassifyRecords + threadIdx.x; // the grid covers the records exactly
     // only the records at the front of a region are in use (a region is a whole number of blocks); what lies behind
     // them is whatever an earlier iteration left there
@@ -1451,11 +1527,16 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
     // (for scenes held in LDS the storage-order walk is the faster one: measured 353 against 610 us per launch)
     const bool ordered = !LDS && !referenceOrder && sc->dev.wide != nullptr;
     unsigned long long* stats = STATS ? w.walkStats : nullptr;
+    const char* runs = std::getenv("PT_TRACE_RUNS");
+    const bool fixedRuns = runs && std::strcmp(runs, "fixed") == 0, takenRuns = runs && std::strcmp(runs, "taken") == 0;
     if (ordered) {
         sc->kt.begin(KernelTimes::kTraceOrdered, stream);
-        hipLaunchKernelGGL((traceOrderedKernel<DYN, STATS>), dim3((slotWaves + shadowWaves) / (kOrderedBlock / 64u)),
-                           dim3(kOrderedBlock), 0, stream, sc->dev, pool, w.counters, parity,
-                           w.samples, shadowCap, slotWaves, stats);
+        // runs taken from counters by as many waves as the chip holds at once (PT_TRACE_RUNS=fixed: a wave per run)
+        const uint32_t allBlocks = (slotWaves + shadowWaves) / (kOrderedBlock / 64u);
+        const uint32_t held = uint32_t(sc->computeUnits) * 4u * PT_ORDERED_WAVES / (kOrderedBlock / 64u);
+        const bool taken = !fixedRuns && held < allBlocks;
+        hipLaunchKernelGGL((traceOrderedKernel<DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, sc->dev,
+                           pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
         // a multiple of kRetryShards blocks: a few per sub-list, more only for large pools
         const uint32_t perList = std::min<uint32_t>(32u, std::max<uint32_t>(1u, pool.retryCap / 1024u));
@@ -1466,8 +1547,15 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         sc->kt.end(stream);
     } else {
         sc->kt.begin(KernelTimes::kTrace, stream);
-        hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS>), gridTrace, block, lds, stream, sc->dev, pool, w.counters, parity,
-                           w.samples, shadowCap, slotWaves, stats);
+        // Static scenes: a wave per run (their walks are short, and the finer hand-out by the hardware is worth more
+        // than filled lanes across runs: 882 against 959 us on the Cornell box); moving surfaces: runs taken from
+        // counters by as many waves as the chip holds (601 against 667 us on the 100 moving spheres) -- eight per
+        // SIMD, fewer when the scene's tables leave room for fewer blocks in LDS.  PT_TRACE_RUNS=fixed|taken overrides.
+        const uint32_t perCu = lds ? std::min<uint32_t>(8u, uint32_t((160u * 1024u) / lds)) : 8u;
+        const uint32_t held = uint32_t(sc->computeUnits) * std::max<uint32_t>(perCu, 1u);
+        const bool taken = (takenRuns || (DYN && !fixedRuns)) && held < gridTrace.x;
+        hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS>), dim3(taken ? held : gridTrace.x), block, lds, stream, sc->dev, pool,
+                           w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
     }
 }
