@@ -227,7 +227,17 @@ constexpr uint32_t kWalkLanes = PT_WALK_LANES;     // keep walking nodes while t
 // that the few items at the front of a draining pool are spread over that many more waves (a wave works a run off
 // 64 at a time: with whole runs the last paths of a batch kept a few hundred waves busy for eight rounds each while
 // the rest of the chip had nothing to do).
-PT_DEV uint32_t runLength(uint32_t cap, uint32_t fill) { return fill * kItemsPerLane <= cap ? 64u : 64u * kItemsPerLane; }
+PT_DEV uint32_t runLength(uint32_t cap, uint32_t fill, uint32_t itemsPerLane = kItemsPerLane)
+{
+    return fill * itemsPerLane <= cap ? 64u : 64u * itemsPerLane;
+}
+// (the runs that the waves of traceOrderedKernel take from a counter are shorter: 256 against 512 items measured 4 %
+// faster on both scenes in memory, the hand-out at the end of the launch is finer; the LDS kernel's stay at 512: with
+// its short walks 256 cost 1.5 %, 128 18 %)
+#ifndef PT_TAKEN_ITEMS_PER_LANE
+#define PT_TAKEN_ITEMS_PER_LANE 4
+#endif
+constexpr uint32_t kTakenItemsPerLane = PT_TAKEN_ITEMS_PER_LANE;
 
 // Two ways of giving the waves of a tracing launch their runs.  Fixed: a wave per run, the launch covers all parts
 // (the hardware hands out blocks as others finish).  Taken: as many waves as the chip holds at once, which take run
@@ -253,12 +263,12 @@ PT_DEV void fillsOfParts(const uint32_t* __restrict__ counters, int parity, uint
 // The next run of the wave's kind: from its part on, the first part with a run left; false when there is none.
 // (Everything here is the same in every lane.)
 PT_DEV bool takeRun(uint32_t* __restrict__ counters, const uint32_t* sFill, RunTaker& t, uint32_t regionCap, uint32_t shadowCap,
-                    uint32_t& pos, uint32_t& endPos)
+                    uint32_t itemsPerLane, uint32_t& pos, uint32_t& endPos)
 {
     for (uint32_t tries = 0; tries < kShards; tries++, t.part = (t.part + 1u) % kShards) {
         const uint32_t cap = t.kind == 0 ? regionCap : shadowCap;
         const uint32_t fill = sFill[t.kind * kShards + t.part];
-        const uint32_t len = runLength(cap, fill);
+        const uint32_t len = runLength(cap, fill, itemsPerLane);
         const uint32_t runs = (fill + len - 1u) / len;
         uint32_t* next = &counters[(kCtrWork + t.kind * kShards + t.part) * kCtrStride];
         if (__hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= runs)
@@ -391,14 +401,14 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
         const uint32_t nIdle = uint32_t(__popcll(idle));
         if (pos >= endPos && !allDone && nIdle >= kRefillLanes) {
-            if (!kindDone && !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos))
+            if (!kindDone && !takeRun(counters, sFill, taker, regionCap, shadowCap, kItemsPerLane, pos, endPos))
                 kindDone = true;
             if (kindDone && nIdle == 64u) {
                 if (!otherKindTried) {
                     otherKindTried = true;
                     taker.kind ^= 1u;
                     taker.part = waveIdx % kShards;
-                    kindDone = !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos);
+                    kindDone = !takeRun(counters, sFill, taker, regionCap, shadowCap, kItemsPerLane, pos, endPos);
                 }
                 allDone = kindDone;
             }
@@ -612,14 +622,14 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
         if (pos >= endPos && !allDone && nIdle >= kRefillLanesOrdered) {
             // the run is worked off: the next one of this kind; the other kind once this one is through and the
             // lanes are empty (the two kinds end differently)
-            if (!kindDone && !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos))
+            if (!kindDone && !takeRun(counters, sFill, taker, regionCap, shadowCap, kTakenItemsPerLane, pos, endPos))
                 kindDone = true;
             if (kindDone && nIdle == 64u) {
                 if (!otherKindTried) {
                     otherKindTried = true;
                     taker.kind ^= 1u;
                     taker.part = waveIdx % kShards;
-                    kindDone = !takeRun(counters, sFill, taker, regionCap, shadowCap, pos, endPos);
+                    kindDone = !takeRun(counters, sFill, taker, regionCap, shadowCap, kTakenItemsPerLane, pos, endPos);
                 }
                 allDone = kindDone;
             }
