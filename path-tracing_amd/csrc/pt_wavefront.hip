@@ -784,22 +784,21 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                 const V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
                 const V3 lo = v3(fminf(A.x, fminf(B.x, C.x)), fminf(A.y, fminf(B.y, C.y)), fminf(A.z, fminf(B.z, C.z)));
                 const V3 hi = v3(fmaxf(A.x, fmaxf(B.x, C.x)), fmaxf(A.y, fmaxf(B.y, C.y)), fmaxf(A.z, fmaxf(B.z, C.z)));
-                float e;
                 if (STATS)
                     nTests++; // (the surface row is fetched whether or not its box is hit)
-                if (aabbEntry(lo, hi, ray, 0.0001f, cull, e)) {
+                // the reference tests the box, then the surface (src/15/bvh.hpp:191-193): both must say yes, so the
+                // surface may be asked first and the box only for the one test in six that hits
+                float a, u, v, e;
+                bool bs;
+                if (triTest(A, B, C, ray, 0.0001f, cull, a, u, v, bs) && aabbEntry(lo, hi, ray, 0.0001f, cull, e)) {
                     gate = e;
-                    float a, u, v;
-                    bool bs;
-                    if (triTest(A, B, C, ray, 0.0001f, cull, a, u, v, bs)) {
-                        h.sid = link;
-                        h.matClass = fbits(r1.w) >> 24;
-                        h.a = a;
-                        h.u = u;
-                        h.v = v;
-                        h.backside = bs;
-                        found = true;
-                    }
+                    h.sid = link;
+                    h.matClass = fbits(r1.w) >> 24;
+                    h.a = a;
+                    h.u = u;
+                    h.v = v;
+                    h.backside = bs;
+                    found = true;
                 }
             }
             if (found) {
