@@ -332,8 +332,12 @@ PT_DEV void addStats(unsigned long long* __restrict__ stats, uint32_t which, uin
         atomicAdd(&stats[which], (unsigned long long)v);
 }
 
+#ifndef PT_TRACE_BLOCK
+#define PT_TRACE_BLOCK 256
+#endif
+constexpr uint32_t kTraceBlock = PT_TRACE_BLOCK; // threads per block of traceKernel
 template <bool DYN, bool LDS, bool STATS>
-__global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
+__global__ void __launch_bounds__(kTraceBlock) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                    float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
                                                    int taken, unsigned long long* __restrict__ stats)
 {
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
     // the queues this iteration's shadeKernel fills were read by the previous launch of this
     // kernel; this launch reads the other set
     if (blockIdx.x == 0)
-        for (uint32_t q = threadIdx.x; q < kShards; q += 256u) {
+        for (uint32_t q = threadIdx.x; q < kShards; q += kTraceBlock) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
             counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
             // the generateKernel before this launch gave path numbers to the places of region q that the
@@ -360,15 +364,15 @@ __global__ void __launch_bounds__(256) traceKernel(DevScene sc, Pool pool, uint3
         __syncthreads();
     if (LDS) {
         const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
-        for (uint32_t i = threadIdx.x; i < nNode4; i += 256u)
+        for (uint32_t i = threadIdx.x; i < nNode4; i += kTraceBlock)
             ldsGeo[i] = sc.nodes[i];
-        for (uint32_t i = threadIdx.x; i < nSurf4; i += 256u)
+        for (uint32_t i = threadIdx.x; i < nSurf4; i += kTraceBlock)
             ldsGeo[nNode4 + i] = sc.surf[i];
         __syncthreads();
         nodes = ldsGeo;
         surf = ldsGeo + nNode4;
     }
-    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 256u + threadIdx.x) >> 6)));
+    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * kTraceBlock + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
     const uint32_t regionCap = pool.nSlots / kShards;
@@ -1528,7 +1532,6 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
     uint32_t slotWaves, shadowWaves;
     traceWavesOf(pool.nSlots, slotWaves, shadowWaves);
-    const dim3 gridTrace((slotWaves + shadowWaves) / 4u);
     const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
     // scenes in memory: nearer child first, then the few rays that leaves open in storage order
     const char* traversal = std::getenv("PT_TRAVERSAL");
@@ -1560,10 +1563,12 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         // than filled lanes across runs: 882 against 959 us on the Cornell box); moving surfaces: runs taken from
         // counters by as many waves as the chip holds (601 against 667 us on the 100 moving spheres) -- eight per
         // SIMD, fewer when the scene's tables leave room for fewer blocks in LDS.  PT_TRACE_RUNS=fixed|taken overrides.
-        const uint32_t perCu = lds ? std::min<uint32_t>(8u, uint32_t((160u * 1024u) / lds)) : 8u;
-        const uint32_t held = uint32_t(sc->computeUnits) * std::max<uint32_t>(perCu, 1u);
-        const bool taken = (takenRuns || (DYN && !fixedRuns)) && held < gridTrace.x;
-        hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS>), dim3(taken ? held : gridTrace.x), block, lds, stream, sc->dev, pool,
+        const uint32_t wavesPerBlock = kTraceBlock / 64u, allBlocks = (slotWaves + shadowWaves) / wavesPerBlock;
+        const uint32_t perCu = std::max<uint32_t>(1u, lds ? std::min<uint32_t>(32u / wavesPerBlock, uint32_t((160u * 1024u) / lds))
+                                                          : 32u / wavesPerBlock);
+        const uint32_t held = uint32_t(sc->computeUnits) * perCu;
+        const bool taken = (takenRuns || (DYN && !fixedRuns)) && held < allBlocks;
+        hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS>), dim3(taken ? held : allBlocks), dim3(kTraceBlock), lds, stream, sc->dev, pool,
                            w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
     }
