@@ -17,7 +17,7 @@ Run in the build container (needs /root/reference and oracle/_ref/libpt_ref.so, 
 
   reindex    the two OBJ files as the importer's parser delivers them (inputs of the re-indexing loop).
 
-    python tools/make_workloads.py [textured|frames|vectors|converged|reindex ...]
+    python tests/golden/make_workloads.py [textured|frames|vectors|converged|reindex ...]
 """
 import ctypes as C
 import math
@@ -27,7 +27,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

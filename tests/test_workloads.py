@@ -1,6 +1,6 @@
 """The file-based benchmark workloads (tests/golden/textured.ptscene: a multi-material OBJ + MTL with image
 textures read by the reference's importer; tests/golden/frames.ptscene: the scene of the reference's animation
-program) against the vectors the reference computed for them (tools/make_workloads.py), on the CPU: the oracle
+program) against the vectors the reference computed for them (tests/golden/make_workloads.py), on the CPU: the oracle
 with the C library's functions reproduces them bit for bit; and the host builder reproduces the reference's tree."""
 import ctypes as C
 import os
