@@ -332,12 +332,11 @@ PT_DEV void addStats(unsigned long long* __restrict__ stats, uint32_t which, uin
         atomicAdd(&stats[which], (unsigned long long)v);
 }
 
-#ifndef PT_TRACE_BLOCK
-#define PT_TRACE_BLOCK 256
-#endif
-constexpr uint32_t kTraceBlock = PT_TRACE_BLOCK; // threads per block of traceKernel
-template <bool DYN, bool LDS, bool STATS>
-__global__ void __launch_bounds__(kTraceBlock) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
+// BLOCK = threads per block: 256, or one wave where the scene's tables are small enough for 32 blocks per compute
+// unit to hold their own copy in LDS (a block keeps its LDS until its slowest wave is through: one-wave blocks
+// measured 2 % faster on the Cornell box, and 30 % slower with the 12.5 KB of the 100 spheres).
+template <bool DYN, bool LDS, bool STATS, uint32_t BLOCK>
+__global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                    float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
                                                    int taken, unsigned long long* __restrict__ stats)
 {
@@ -345,7 +344,7 @@ __global__ void __launch_bounds__(kTraceBlock) traceKernel(DevScene sc, Pool poo
     // the queues this iteration's shadeKernel fills were read by the previous launch of this
     // kernel; this launch reads the other set
     if (blockIdx.x == 0)
-        for (uint32_t q = threadIdx.x; q < kShards; q += kTraceBlock) {
+        for (uint32_t q = threadIdx.x; q < kShards; q += BLOCK) {
             counters[(kCtrShadow + parity * kShards + q) * kCtrStride] = 0;
             counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
             // the generateKernel before this launch gave path numbers to the places of region q that the
@@ -364,15 +363,15 @@ __global__ void __launch_bounds__(kTraceBlock) traceKernel(DevScene sc, Pool poo
         __syncthreads();
     if (LDS) {
         const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
-        for (uint32_t i = threadIdx.x; i < nNode4; i += kTraceBlock)
+        for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK)
             ldsGeo[i] = sc.nodes[i];
-        for (uint32_t i = threadIdx.x; i < nSurf4; i += kTraceBlock)
+        for (uint32_t i = threadIdx.x; i < nSurf4; i += BLOCK)
             ldsGeo[nNode4 + i] = sc.surf[i];
         __syncthreads();
         nodes = ldsGeo;
         surf = ldsGeo + nNode4;
     }
-    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * kTraceBlock + threadIdx.x) >> 6)));
+    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * BLOCK + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
     const uint32_t regionCap = pool.nSlots / kShards;
@@ -1563,13 +1562,18 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         // than filled lanes across runs: 882 against 959 us on the Cornell box); moving surfaces: runs taken from
         // counters by as many waves as the chip holds (601 against 667 us on the 100 moving spheres) -- eight per
         // SIMD, fewer when the scene's tables leave room for fewer blocks in LDS.  PT_TRACE_RUNS=fixed|taken overrides.
-        const uint32_t wavesPerBlock = kTraceBlock / 64u, allBlocks = (slotWaves + shadowWaves) / wavesPerBlock;
+        const bool waveBlocks = LDS && !DYN && lds * 32u <= 160u * 1024u;
+        const uint32_t wavesPerBlock = waveBlocks ? 1u : 4u, allBlocks = (slotWaves + shadowWaves) / wavesPerBlock;
         const uint32_t perCu = std::max<uint32_t>(1u, lds ? std::min<uint32_t>(32u / wavesPerBlock, uint32_t((160u * 1024u) / lds))
                                                           : 32u / wavesPerBlock);
         const uint32_t held = uint32_t(sc->computeUnits) * perCu;
         const bool taken = (takenRuns || (DYN && !fixedRuns)) && held < allBlocks;
-        hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS>), dim3(taken ? held : allBlocks), dim3(kTraceBlock), lds, stream, sc->dev, pool,
-                           w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
+        if (waveBlocks)
+            hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS, (LDS && !DYN) ? 64u : 256u>), dim3(taken ? held : allBlocks), dim3(64), lds, stream,
+                               sc->dev, pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
+        else
+            hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS, 256u>), dim3(taken ? held : allBlocks), dim3(256), lds, stream, sc->dev, pool,
+                               w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
     }
 }
