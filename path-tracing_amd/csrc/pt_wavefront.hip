@@ -115,6 +115,7 @@ template <uint32_t WAVES>
 PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bool wantB,
                           uint32_t* lds /* 2 * (WAVES + 1) words */, uint32_t& posA, uint32_t& posB)
 {
+    static_assert(WAVES >= 2, "threads 0 and 64 make the two reservations: a block needs two waves");
     const uint64_t maskA = __builtin_amdgcn_ballot_w64(wantA), maskB = __builtin_amdgcn_ballot_w64(wantB);
     const uint32_t wave = threadIdx.x >> 6, lane = laneId();
     uint32_t* ldsA = lds;
