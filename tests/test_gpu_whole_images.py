@@ -34,3 +34,24 @@ def test_whole_image(name, oracle):
     want = oracle.render(C.byref(d), cam, p, math_mode=1)
     assert np.isfinite(got).all() and got.mean() > 0.01
     assert differing_pixels(got, want) == 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "frames1", "mesh1000"])
+def test_fixed_and_taken_runs_give_the_same_image(name):
+    """PT_TRACE_RUNS=fixed|taken only changes which wave traces which ray: the image is the same bit for bit, on the
+    LDS kernel (static and moving surfaces) and on the nearer-child-first kernel, at a size where both ways differ."""
+    import os
+    scene, cam, label, sqrt_spp, extra = workloads.load(name)
+    W, H = extra.get("width", 1920), extra.get("height", 1080)
+    t0, t1 = extra["frames"][0] if "frames" in extra else (0.0, 0.0)
+    p = pt.make_params(W, H, 1, seed=3, t0=t0, t1=t1)
+    images = {}
+    with pt.DeviceScene(scene) as dev:
+        dev.build_bvh_device(t0, t1)
+        for mode in ("fixed", "taken"):
+            os.environ["PT_TRACE_RUNS"] = mode
+            try:
+                images[mode] = dev.render(cam, p)
+            finally:
+                del os.environ["PT_TRACE_RUNS"]
+    assert differing_pixels(images["fixed"], images["taken"]) == 0
