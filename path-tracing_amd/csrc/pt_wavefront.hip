@@ -209,7 +209,7 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #define PT_REFILL_LANES 32
 #endif
 #ifndef PT_WALK_LANES
-#define PT_WALK_LANES 24
+#define PT_WALK_LANES 16
 #endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
