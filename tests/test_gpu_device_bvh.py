@@ -234,3 +234,43 @@ def test_degenerate_inputs(oracle):
                         del os.environ["PT_NO_LDS_SCENE"]
                 assert np.array_equal(got.view(np.uint32),
                                       oracle.render_samples(C.byref(d), cam, q, math_mode=1).view(np.uint32)), (variant, env)
+
+
+def test_surfaces_of_very_different_sizes(oracle):
+    """3 000 spheres with radii over five orders of magnitude, a third of them in one tight cluster and a hundred
+    identical ones inside it: bins that hold almost everything, planes that separate nothing, subtrees of one wave
+    and passes over large nodes -- the tree is valid and both device walks agree with the oracle on it."""
+    rng = np.random.default_rng(7)
+    s = pt.FlatScene()
+    grey = s.material_lambertian(s.texture_constant((0.6, 0.6, 0.6)))
+    light = s.material_light((5.0, 5.0, 5.0))
+    n = 3000
+    centres = rng.uniform(-50.0, 50.0, (n, 3))
+    centres[: n // 3] = rng.normal(0.0, 0.05, (n // 3, 3)) + np.array([3.0, 1.0, -2.0])
+    radii = 10.0 ** rng.uniform(-4.0, 1.0, n)
+    radii[: n // 3] *= 1e-2
+    for k in range(n):
+        s.add_sphere(tuple(float(c) for c in centres[k]), float(radii[k]), grey)
+    for _ in range(100):
+        s.add_sphere((3.0, 1.0, -2.0), 0.01, grey)
+    s.add_sphere((0.0, 80.0, 0.0), 10.0, light, is_light=True)
+    s.build_bvh()
+    cam = scenes.build("spheres")[1]
+    q = pt.make_params(48, 32, 2, seed=6)
+    for env in (None, "1"):
+        if env:
+            os.environ["PT_NO_LDS_SCENE"] = env
+        try:
+            with pt.DeviceScene(s) as dev:
+                dev.build_bvh_device()
+                nodes = dev.get_bvh()
+                check_tree(nodes, len(s.surfaces))
+                flat_nodes, s.nodes = s.nodes, nodes
+                d = s.desc()
+                got = dev.render_samples(cam, q)
+                want = oracle.render_samples(C.byref(d), cam, q, math_mode=1)
+                s.nodes = flat_nodes
+        finally:
+            if env:
+                del os.environ["PT_NO_LDS_SCENE"]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), env
