@@ -79,16 +79,23 @@ struct WavefrontBuffers {
 // streams have been synchronised) adds the elapsed times to the sums.
 struct KernelTimes {
     enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kTraceOrdered, kTraceRetry, kKinds };
+    struct Span {
+        size_t start, stop; // indices into `events`
+        int kind;
+    };
     bool enabled = false;
-    std::vector<hipEvent_t> events; // pairs: start, stop
-    std::vector<int> kinds;         // kind of pair i
-    size_t used = 0;                // events in use
+    std::vector<hipEvent_t> events;
+    std::vector<Span> spans; // one per launch since the last collect()
+    size_t used = 0;         // events in use
+    bool chained = false;    // the last thing put on the stream was the stop event of a launch
     double ms[kKinds] = {};
     uint64_t launches[kKinds] = {};
 
     void reset()
     {
         used = 0;
+        spans.clear();
+        chained = false;
         for (int k = 0; k < kKinds; k++) {
             ms[k] = 0;
             launches[k] = 0;
@@ -105,38 +112,53 @@ struct KernelTimes {
         (void)hipEventRecord(events[used], stream);
         used++;
     }
+    // Launches that follow one another on the stream share an event: the stop of one is the start of the next (an
+    // event between two kernels costs a few microseconds of the stream's time; two per launch were 1.9 % of a
+    // Cornell render).  Whoever puts anything else on the stream in between calls unchain().
     void begin(int kind, hipStream_t stream)
     {
         if (!enabled)
             return;
-        if (kinds.size() <= used / 2)
-            kinds.resize(used / 2 + 1);
-        kinds[used / 2] = kind;
-        record(stream);
+        if (!chained || used == 0)
+            record(stream);
+        if (used == 0)
+            return; // (no event could be created)
+        spans.push_back(Span{ used - 1, used - 1, kind });
+        chained = false;
     }
     void end(hipStream_t stream)
     {
-        if (enabled)
-            record(stream);
+        if (!enabled || spans.empty())
+            return;
+        const size_t before = used;
+        record(stream);
+        if (used > before) {
+            spans.back().stop = used - 1;
+            chained = true;
+        }
     }
+    void unchain() { chained = false; }
     void collect()
     {
-        for (size_t i = 0; i + 1 < used; i += 2) {
+        for (const Span& sp : spans) {
             float t = 0.0f;
-            if (hipEventElapsedTime(&t, events[i], events[i + 1]) == hipSuccess) {
-                ms[kinds[i / 2]] += double(t);
-                launches[kinds[i / 2]]++;
+            if (sp.stop != sp.start && hipEventElapsedTime(&t, events[sp.start], events[sp.stop]) == hipSuccess) {
+                ms[sp.kind] += double(t);
+                launches[sp.kind]++;
             }
         }
+        spans.clear();
         used = 0;
+        chained = false;
     }
     void release()
     {
         for (hipEvent_t e : events)
             (void)hipEventDestroy(e);
         events.clear();
-        kinds.clear();
+        spans.clear();
         used = 0;
+        chained = false;
     }
 };
 

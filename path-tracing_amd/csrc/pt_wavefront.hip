@@ -1602,6 +1602,7 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
     const uint32_t nSlots = pools[0].nSlots;
     // (no paths yet: no records in use at the front of any region, so the first tracing and classifying launches
     // look at nothing and the pools need no clearing)
+    sc->kt.unchain(); // (what follows on the stream is not a timed launch)
     HIP_TRY(hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream));
     const uint64_t maxIters = (uint64_t(b.totalIds) / nSlots + 2) * uint64_t(a.pp.maxSegments + 2) + 64;
     const bool dyn = sc->hasDynamic;
@@ -1697,6 +1698,7 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
     int rc = PT_OK;
     Pool pools[2];
     carvePools(w.pool, uint32_t(nSlots), pools);
+    sc->kt.unchain();
     HIP_TRY(hipEventRecord(sc->evStart, stream));
     for (uint32_t s = 0; s < nsTotal; s += uint32_t(perBatch)) {
         Batch b;
@@ -1717,6 +1719,7 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
             HIP_TRY(hipGetLastError());
         }
     }
+    sc->kt.unchain();
     HIP_TRY(hipEventRecord(sc->evStop, stream));
     sc->timed = true;
     return PT_OK;
@@ -1771,7 +1774,9 @@ int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, co
     }
     hipLaunchKernelGGL(fillRaysKernel, dim3(uint32_t(nSlots / 256u)), dim3(256), 0, stream, pools[0], n, d_origins, d_dirs,
                        d_times);
+    scene->kt.unchain();
     launchTraceFor(scene, w, pools[0], stream, 0, scene->hasDynamic, sceneFitsLds(scene));
+    scene->kt.unchain();
     hipLaunchKernelGGL(collectHitsKernel, dim3(uint32_t((n + 255u) / 256u)), dim3(256), 0, stream, scene->dev, pools[0], n,
                        d_out);
     HIP_TRY(hipGetLastError());
