@@ -1274,7 +1274,17 @@ __device__ inline Ray cameraRay(const pt_camera& cam, float p, float q, float t0
     }
     V3 O = v3(lens.x, lens.y, 0.0f);
     V3 D = P - O;
-    float t = mixf(t0, t1, rng.in01());
+    // (a still frame: the draw is made -- the generator moves on -- but t0 + u * (t1 - t0) with t1 - t0 = +0 is
+    // t0 + 0 for every u in [0, 1), so its value need not be worked out)
+    float t;
+    if (t0 == t1) {
+        rng.n++;
+        if (COUNT)
+            rng.cnt->draws++;
+        t = mixf(t0, t1, 0.0f);
+    } else {
+        t = mixf(t0, t1, rng.in01());
+    }
     if (cam.has_animation) {
         Xform T = animationAt<PM>(cam.animation, t);
         O = apply(T, O);
