@@ -49,7 +49,7 @@ struct DevMesh {
 // their first child at index + 1.
 // surf: 3 x float4 per surface; triangles (A.xyz, bits kind), (B.xyz, bits
 // mesh | material type << 24), (C.xyz, bits triangle-in-mesh); spheres
-// (centre.xyz, bits kind), (radius, bits sphere, -, bits material type << 24), unused.  surfAttr and matConst repeat, per
+// (centre.xyz, bits kind), (radius, bits sphere, bits animation number, bits material type << 24), unused.  surfAttr and matConst repeat, per
 // surface and per material, what shading would otherwise reach through two or
 // three dependent table reads (mesh -> index list -> vertices; material ->
 // texture -> value).
@@ -85,6 +85,7 @@ struct DevScene {
     uint32_t n_nodes;
     uint32_t n_surfaces;
     uint32_t n_lights;
+    uint32_t n_animations;
     pt_envmap envmap;
 };
 
@@ -539,9 +540,10 @@ PT_DEV void sphereCR(const DevScene& sc, uint32_t sid, float time, V3& c, float&
 
 // Surface::hit without the record: triangle or sphere.  DYN = false promises that the scene
 // has no surface whose pose depends on the ray time (no two-key animation), and drops that code.
+// `anims` = the animation table (sc.animations, or a copy of it that a kernel keeps in LDS).
 template <bool DYN>
-PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uint32_t sid, const Ray& ray, float amin,
-                        float amax, HitLite& out)
+PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, const pt_animation* __restrict__ anims, uint32_t sid,
+                        const Ray& ray, float amin, float amax, HitLite& out)
 {
     float4 r0 = surf[3 * sid + 0];
     float4 r1 = surf[3 * sid + 1];
@@ -551,7 +553,7 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
         V3 A = v3(r0.x, r0.y, r0.z), B = v3(r1.x, r1.y, r1.z), C = v3(r2.x, r2.y, r2.z);
         if (DYN && kind == kTriDynamic) {
             const DevMesh& m = sc.meshes[fbits(r1.w) & kMeshMask];
-            Xform T = animationAt<PM>(sc.animations[m.animation], ray.time);
+            Xform T = animationAt<PM>(anims[m.animation], ray.time);
             A = apply(T, A);
             B = apply(T, B);
             C = apply(T, C);
@@ -571,8 +573,8 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
     V3 c = v3(r0.x, r0.y, r0.z);
     float r = r1.x;
     if (DYN && kind == kSphDynamic) {
-        const pt_sphere& q = sc.spheres[fbits(r1.y)];
-        Xform T = animationAt<PM>(sc.animations[q.animation], ray.time);
+        // (the sphere's animation number travels in its row: no look into the sphere table)
+        Xform T = animationAt<PM>(anims[fbits(r1.z)], ray.time);
         c = apply(T, c);
         r *= T.scaling.x;
     }
@@ -586,6 +588,13 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
     out.backside = false;
     out.matClass = fbits(r1.w) >> 24;
     return true;
+}
+
+template <bool DYN>
+PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uint32_t sid, const Ray& ray, float amin,
+                        float amax, HitLite& out)
+{
+    return surfaceTest<DYN>(sc, surf, sc.animations, sid, ray, amin, amax, out);
 }
 
 // BVHTreeLinear::hit, reference src/15/bvh.hpp:183-213.  The reference walks

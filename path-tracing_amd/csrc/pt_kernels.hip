@@ -522,7 +522,8 @@ try {
                 }
             }
             surf[3 * i + 0] = make_float4(c.x, c.y, c.z, bitsf(kind));
-            surf[3 * i + 1] = make_float4(r, bitsf(s.owner), 0.0f, bitsf(matClassOf(q.material) << 24));
+            // (radius, sphere number, animation number -- what the test of a moving sphere looks up --, type of material)
+            surf[3 * i + 1] = make_float4(r, bitsf(s.owner), bitsf(uint32_t(q.animation)), bitsf(matClassOf(q.material) << 24));
             surf[3 * i + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             surfAttr[i] = make_uint4(s.owner, 0u, 0u, uint32_t(q.material) | (materialNeeds(q.material, 0) << 24));
         }
@@ -609,6 +610,7 @@ try {
     dev.textures = dTex;
     dev.texels = dTexels;
     dev.animations = dAnims;
+    dev.n_animations = uint32_t(d->n_animations);
     dev.n_nodes = uint32_t(d->n_bvh_nodes);
     dev.n_surfaces = uint32_t(d->n_surfaces);
     dev.n_lights = uint32_t(d->n_lights);

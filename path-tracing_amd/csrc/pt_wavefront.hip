@@ -384,33 +384,52 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     fillsOfParts(counters, parity, sFill);
     const float4* nodes = sc.nodes;
     const float4* surf = sc.surf;
-    if (!LDS)
-        __syncthreads();
+    const pt_animation* anims = sc.animations;
+    __syncthreads();
+    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * BLOCK + threadIdx.x) >> 6)));
+    const uint32_t regionCap = pool.nSlots / kShards;
+    uint32_t pos = 0, endPos = 0; // the rest of the run in hand
+    bool fixedRunHere = false;
+    if (!taken) {
+        // fixed runs: a block none of whose waves has a run (most of them while the pool drains) is through before it
+        // copies any tables
+        fixedRunHere = fixedRun(sFill, waveIdx >= slotWaves ? 1u : 0u, waveIdx >= slotWaves ? waveIdx - slotWaves : waveIdx, regionCap,
+                                shadowCap, pos, endPos);
+        if (!__syncthreads_or(fixedRunHere ? 1 : 0))
+            return;
+    }
     if (LDS) {
         const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
         for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK)
             ldsGeo[i] = sc.nodes[i];
         for (uint32_t i = threadIdx.x; i < nSurf4; i += BLOCK)
             ldsGeo[nNode4 + i] = sc.surf[i];
+        if (DYN) {
+            // moving surfaces: the poses they move between as well (a test of one reads its two keys)
+            static_assert(sizeof(pt_animation) % 4 == 0, "copied by words");
+            uint32_t* to = reinterpret_cast<uint32_t*>(ldsGeo + nNode4 + nSurf4);
+            const uint32_t* from = reinterpret_cast<const uint32_t*>(sc.animations);
+            const uint32_t nWords = sc.n_animations * uint32_t(sizeof(pt_animation) / 4);
+            for (uint32_t i = threadIdx.x; i < nWords; i += BLOCK)
+                to[i] = from[i];
+            anims = reinterpret_cast<const pt_animation*>(to);
+        }
         __syncthreads();
         nodes = ldsGeo;
         surf = ldsGeo + nNode4;
     }
-    const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * BLOCK + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
-    const uint32_t regionCap = pool.nSlots / kShards;
     // 0: rays of paths (items are pool records), 1: shadow rays (items are queue entries); half of the waves begin
     // with either kind and go over to the other when theirs is worked off and their lanes are empty (see takeRun)
     // taken runs: half of the waves begin with either kind and go over to the other when theirs is worked off and
     // their lanes are empty; fixed runs: the first slotWaves waves have the pool's regions, the others the queues
     RunTaker taker = { taken ? (waveIdx / kShards) & 1u : (waveIdx >= slotWaves ? 1u : 0u), waveIdx % kShards };
     bool kindDone = false, otherKindTried = false, allDone = false;
-    uint32_t pos = 0, endPos = 0; // the rest of the run in hand
     if (!taken) {
         kindDone = otherKindTried = allDone = true;
-        if (!fixedRun(sFill, taker.kind, taker.kind ? waveIdx - slotWaves : waveIdx, regionCap, shadowCap, pos, endPos))
-            return;
+        if (!fixedRunHere)
+            return; // (no barrier follows)
     }
 
     bool have = false;
@@ -506,7 +525,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
             }
         }
         if (have && pending != kInner) {
-            if (surfaceTest<DYN>(sc, surf, pending, ray, 0.0001f, amax, best))
+            if (surfaceTest<DYN>(sc, surf, anims, pending, ray, 0.0001f, amax, best))
                 amax = best.a;
             pending = kInner;
             if (STATS)
@@ -1002,8 +1021,10 @@ constexpr uint32_t kClassifyBlock = 1024;
 #endif
 constexpr uint32_t kClassifyChunks = PT_CLASSIFY_CHUNKS;
 constexpr uint32_t kClassifyRecords = kClassifyBlock * kClassifyChunks; // records per block
+// The grid has blocksPerRegion blocks for the front of each region: all of a region (regionCap / kClassifyRecords), or
+// fewer once the host knows that no region has more than so many records in use (see runBatch).
 __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters,
-                                                                 float* __restrict__ samples)
+                                                                 float* __restrict__ samples, FastDiv blocksPerRegion)
 {
     // hits go to the list ordered by the type of their material within the block's records, so that the
     // 64 entries a wave of shadeHitsKernel takes mostly run the same material code
@@ -1014,12 +1035,12 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
         counters[(kCtrRetry + threadIdx.x) * kCtrStride] = 0; // the retry lists of this iteration have been worked off
     if (blockIdx.x == 0 && threadIdx.x < 2u * kShards)
         counters[(kCtrWork + threadIdx.x) * kCtrStride] = 0; // the next tracing launch hands out its runs from the start
-    const uint32_t slot0 = blockIdx.x * kClassifyRecords + threadIdx.x; // the grid covers the records exactly
     // only the records at the front of a region are in use (a region is a whole number of blocks); what lies behind
     // them is whatever an earlier iteration left there
-    const uint32_t regionCap = pool.nSlots / kShards, region = blockIdx.x * kClassifyRecords / regionCap;
+    const uint32_t regionCap = pool.nSlots / kShards, region = blocksPerRegion.div(blockIdx.x);
+    const uint32_t inRegion0 = (blockIdx.x - region * blocksPerRegion.d) * kClassifyRecords + threadIdx.x;
+    const uint32_t slot0 = region * regionCap + inRegion0;
     const uint32_t inUse = counters[(kCtrOcc + region) * kCtrStride];
-    const uint32_t inRegion0 = slot0 - region * regionCap;
     if (inRegion0 - threadIdx.x >= inUse)
         return;
     uint8_t cls[kClassifyChunks];
@@ -1120,18 +1141,21 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     }
 }
 
+// The grid has blocksPerShard blocks for the front of each shard's list: the whole list (listCap / kShadeBlock), or
+// fewer once the host knows that no list can be longer (see runBatch).
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
                                                                        uint32_t* __restrict__ counters, int parity,
-                                                                       float* __restrict__ samples, uint32_t shadowCap)
+                                                                       float* __restrict__ samples, uint32_t shadowCap,
+                                                                       FastDiv blocksPerShard)
 {
     __shared__ uint32_t lds[2 * (kShadeBlock / 64 + 1)];
-    // the block's entries lie inside one shard's list (listCap is a multiple of the block size)
-    const uint32_t first = blockIdx.x * kShadeBlock;
-    const uint32_t shard = first / pool.listCap;
+    // the block's entries lie inside one shard's list
+    const uint32_t shard = blocksPerShard.div(blockIdx.x);
+    const uint32_t first = (blockIdx.x - shard * blocksPerShard.d) * kShadeBlock; // within the list
     const uint32_t fill = counters[(kCtrHit + shard) * kCtrStride];
-    if (first - shard * pool.listCap >= fill)
+    if (first >= fill)
         return; // the whole block lies beyond the list
-    const uint32_t entry = first - shard * pool.listCap + threadIdx.x;
+    const uint32_t entry = first + threadIdx.x;
     const bool valid = entry < fill;
     const uint32_t slot = valid ? pool.hitList[size_t(shard) * pool.listCap + entry] : 0u;
     bool finished = false;
@@ -1275,12 +1299,14 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
 #ifndef PT_GENERATE_ROOT_TEST
 #define PT_GENERATE_ROOT_TEST 1
 #endif
+// The grid has blocksPerRegion blocks for the front of each region: all of a region (regionCap / 256), or one once the
+// host knows that every path has been started (the launch then only notes the records in use).
 __global__ void __launch_bounds__(256) generateKernel(DevScene sc, Pool next, RenderArgs a, Batch b, uint32_t* __restrict__ counters,
-                                                      float* __restrict__ samples)
+                                                      float* __restrict__ samples, FastDiv blocksPerRegion)
 {
     const uint32_t regionCap = next.nSlots / kShards; // a multiple of 256
-    const uint32_t first = blockIdx.x * 256u;
-    const uint32_t shard = first / regionCap;
+    const uint32_t shard = blocksPerRegion.div(blockIdx.x);
+    const uint32_t first = shard * regionCap + (blockIdx.x - shard * blocksPerRegion.d) * 256u;
     const uint32_t goingOn = counters[(kCtrLive + shard) * kCtrStride];
     const uint32_t inRegion = first - shard * regionCap + threadIdx.x;
     // records in use at the front of the region once this launch is through: the paths that go on and the new ones
@@ -1540,13 +1566,21 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
     return PT_OK;
 }
 
-// node + surface tables up to this size are traced from LDS
+// node + surface tables up to this size are traced from LDS; with moving surfaces the animation table goes there
+// too, and all three may take twice as much
 constexpr size_t kLdsGeoLimit = 16 * 1024;
+
+// bytes of LDS that the tables of a scene traced from LDS take
+size_t ldsTableBytes(const pt_scene* sc)
+{
+    return (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16
+        + (sc->hasDynamic ? size_t(sc->dev.n_animations) * sizeof(pt_animation) : 0);
+}
 
 bool sceneFitsLds(const pt_scene* sc)
 {
     return (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 <= kLdsGeoLimit
-        && std::getenv("PT_NO_LDS_SCENE") == nullptr;
+        && ldsTableBytes(sc) <= 2 * kLdsGeoLimit && std::getenv("PT_NO_LDS_SCENE") == nullptr;
 }
 
 // the tracing step of one iteration
@@ -1557,7 +1591,7 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
     const uint32_t shadowCap = shadowCapOf(pool.nSlots);
     uint32_t slotWaves, shadowWaves;
     traceWavesOf(pool.nSlots, slotWaves, shadowWaves);
-    const size_t lds = LDS ? (size_t(2) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16 : 0;
+    const size_t lds = LDS ? ldsTableBytes(sc) : 0;
     // scenes in memory: nearer child first, then the few rays that leaves open in storage order
     const char* traversal = std::getenv("PT_TRAVERSAL");
     const bool referenceOrder = traversal && std::strcmp(traversal, "reference") == 0;
@@ -1633,32 +1667,38 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
     const bool dyn = sc->hasDynamic;
     const bool lds = sceneFitsLds(sc);
     const uint32_t shadowCap = shadowCapOf(nSlots);
-    const dim3 gridSlots(nSlots / 256u), block(256);
+    const dim3 block(256);
     // the first tracing launch has no generateKernel before it: nothing to add to the path numbers
     for (uint32_t q = 0; q < kShards; q++)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrLive + q) * kCtrStride),
                                   int(nSlots / kShards), 1, stream));
     bool exhaustedBefore = false; // every path number had been handed out at the previous check already
     uint64_t iter = 0;
+    // Blocks per region (per list) of the classifying, shading and generating launches: all of it while paths are
+    // being started.  Once the last one has been, the pool only drains -- with Russian roulette for a hundred
+    // iterations and more, the last ones with a handful of paths -- and the counts read back bound what any later
+    // iteration can hold, so the launches shrink to that: an iteration on an almost empty pool costs 80 us with
+    // grids over 16 M records, most of it the hardware handing out blocks that find nothing to do.
+    const uint32_t regionCap = nSlots / kShards;
+    uint32_t classifyBlocks = regionCap / kClassifyRecords, shadeBlocks = pools[0].listCap / kShadeBlock, generateBlocks = regionCap / 256u;
+    int checkEvery = 16; // iterations between two looks at the counters
     for (;;) {
-        // the counters are read back every 16 iterations while paths are being started, every other
-        // iteration once the last one has been (the pool then drains within a few iterations)
-        const int checkEvery = exhaustedBefore ? 2 : 16;
         for (int k = 0; k < checkEvery; k++, iter++) {
             const int parity = int(iter & 1);
             const Pool& cur = pools[iter & 1];
             const Pool& next = pools[(iter + 1) & 1];
             launchTraceFor(sc, w, cur, stream, parity, dyn, lds);
             sc->kt.begin(KernelTimes::kClassify, stream);
-            hipLaunchKernelGGL(classifyKernel, dim3(nSlots / kClassifyRecords), dim3(kClassifyBlock), 0, stream, sc->dev, cur,
-                               w.counters, w.samples);
+            hipLaunchKernelGGL(classifyKernel, dim3(classifyBlocks * kShards), dim3(kClassifyBlock), 0, stream, sc->dev, cur,
+                               w.counters, w.samples, FastDiv(classifyBlocks));
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
-            hipLaunchKernelGGL(shadeHitsKernel, dim3(pools[0].listCap / kShadeBlock * kShards), dim3(kShadeBlock), 0, stream,
-                               sc->dev, cur, next, a.pp, w.counters, parity, w.samples, shadowCap);
+            hipLaunchKernelGGL(shadeHitsKernel, dim3(shadeBlocks * kShards), dim3(kShadeBlock), 0, stream, sc->dev, cur, next, a.pp,
+                               w.counters, parity, w.samples, shadowCap, FastDiv(shadeBlocks));
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kGenerate, stream);
-            hipLaunchKernelGGL(generateKernel, gridSlots, block, 0, stream, sc->dev, next, a, b, w.counters, w.samples);
+            hipLaunchKernelGGL(generateKernel, dim3(generateBlocks * kShards), block, 0, stream, sc->dev, next, a, b, w.counters,
+                               w.samples, FastDiv(generateBlocks));
             sc->kt.end(stream);
         }
         HIP_TRY(hipGetLastError());
@@ -1667,12 +1707,12 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
         sc->kt.collect();
         // finished when the last iteration shaded nothing and every path number had been handed out
         // well before it (so that its generateKernel cannot have started a path)
-        uint64_t alive = 0;
+        uint64_t alive = 0, goingOnAll = 0;
         bool exhausted = true;
-        const uint32_t regionCap = nSlots / kShards;
         for (uint32_t q = 0; q < kShards; q++) {
             const uint32_t goingOn = w.hostCounters[(kCtrLive + q) * kCtrStride];
             alive += w.hostCounters[(kCtrHit + q) * kCtrStride] + goingOn;
+            goingOnAll += goingOn;
             // path numbers of shard q: the counter as of the last tracing launch + the last generateKernel's
             const uint64_t handedOut = uint64_t(w.hostCounters[q * kCtrStride]) + (regionCap - goingOn);
             if ((handedOut >> 6) * kShards + q < (b.totalIds >> 6))
@@ -1681,6 +1721,17 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
         if (exhaustedBefore && alive == 0)
             break;
         exhaustedBefore = exhausted;
+        if (exhausted) {
+            // No launch starts a path any more.  A list of hits is made from the records of every region, and the paths
+            // of a list go on in one region, so what bounds a region and a list from here on is the number of all paths
+            // that go on; generateKernel is left with noting the records in use, which the first block of a region does.
+            classifyBlocks = uint32_t(std::min<uint64_t>(classifyBlocks, std::max<uint64_t>(1u, (goingOnAll + kClassifyRecords - 1u) / kClassifyRecords)));
+            shadeBlocks = uint32_t(std::min<uint64_t>(shadeBlocks, std::max<uint64_t>(1u, (goingOnAll + kShadeBlock - 1u) / kShadeBlock)));
+            generateBlocks = 1;
+            // the paths that are left halve every few iterations: look again sooner the fewer they are (a look costs
+            // the stream a pause, an iteration on an empty pool a few launches)
+            checkEvery = goingOnAll > 100000 ? 16 : goingOnAll > 1000 ? 8 : goingOnAll > 30 ? 4 : 2;
+        }
         if (iter > maxIters)
             return fail(PT_ERR_DEVICE, "wavefront renderer did not finish within its iteration bound");
     }
