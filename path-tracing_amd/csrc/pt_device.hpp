@@ -1303,16 +1303,21 @@ __device__ inline Ray cameraRay(const pt_camera& cam, float p, float q, float t0
 }
 
 // the ray of sample `smp` of pixel (x, y): reference src/15/pathtracer.cpp:211-215
+// (i, j) = the sample's stratum: smp / sqrt_spp and smp % sqrt_spp
 template <bool COUNT>
-__device__ inline Ray sampleRay(const pt_camera& cam, const pt_render_params& p, int x, int y, int smp, Rng<COUNT>& rng)
+__device__ inline Ray sampleRayOfStratum(const pt_camera& cam, const pt_render_params& p, int x, int y, int i, int j, Rng<COUNT>& rng)
 {
-    int i = smp / p.sqrt_spp;
-    int j = smp % p.sqrt_spp;
     float sp = (i + rng.in01()) / p.sqrt_spp;
     float sq = (j + rng.in01()) / p.sqrt_spp;
     float pp = (x + sp) / p.width;
     float q = (y + sq) / p.height;
     return cameraRay<COUNT>(cam, pp, q, p.t0, p.t1, rng);
+}
+
+template <bool COUNT>
+__device__ inline Ray sampleRay(const pt_camera& cam, const pt_render_params& p, int x, int y, int smp, Rng<COUNT>& rng)
+{
+    return sampleRayOfStratum<COUNT>(cam, p, x, y, smp / p.sqrt_spp, smp % p.sqrt_spp, rng);
 }
 
 } // namespace ptd

@@ -99,7 +99,7 @@ struct FastDiv {
 
 struct Batch {
     uint32_t tilesX, tilesY; // 8x8 pixel tiles covering the tile rectangle
-    FastDiv byTilesX, byNS;
+    FastDiv byTilesX, byNS, bySqrtSpp;
     uint32_t nS;             // samples per pixel in this batch
     uint32_t sFirst;         // first sample index of the batch
     uint32_t npix;           // pixels of the tile rectangle
@@ -1346,7 +1346,8 @@ __global__ void __launch_bounds__(256) generateKernel(DevScene sc, Pool next, Re
     rng.key = pt_rng_key(a.p.seed, uint64_t(y) * a.p.width + x, uint64_t(smp));
     rng.n = 0;
     rng.cnt = nullptr;
-    Ray ray = sampleRay<false>(a.cam, a.p, x, y, smp, rng);
+    const uint32_t stratumRow = b.bySqrtSpp.div(uint32_t(smp));
+    Ray ray = sampleRayOfStratum<false>(a.cam, a.p, x, y, int(stratumRow), smp - int(stratumRow) * a.p.sqrt_spp, rng);
 #if PT_GENERATE_ROOT_TEST
     // A camera ray that misses the box of the whole tree ends here as the tracing and classifying kernels would
     // end it (the walk's first step is this very test, reference src/15/bvh.hpp:183-213, and a miss adds the
@@ -1783,6 +1784,7 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
         b.nS = std::min<uint32_t>(uint32_t(perBatch), nsTotal - s);
         b.byTilesX = FastDiv(tilesX);
         b.byNS = FastDiv(b.nS);
+        b.bySqrtSpp = FastDiv(uint32_t(a.p.sqrt_spp));
         b.sFirst = uint32_t(a.s0) + s;
         b.npix = uint32_t(npix);
         b.totalIds = uint32_t(idsPerSample * b.nS);
