@@ -1682,7 +1682,8 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
     // grids over 16 M records, most of it the hardware handing out blocks that find nothing to do.
     const uint32_t regionCap = nSlots / kShards;
     uint32_t classifyBlocks = regionCap / kClassifyRecords, shadeBlocks = pools[0].listCap / kShadeBlock, generateBlocks = regionCap / 256u;
-    int checkEvery = 16; // iterations between two looks at the counters
+    // iterations between two looks at the counters (a batch that fits the pool has started all its paths at once)
+    int checkEvery = b.totalIds <= nSlots ? 2 : 16;
     for (;;) {
         for (int k = 0; k < checkEvery; k++, iter++) {
             const int parity = int(iter & 1);
