@@ -1121,23 +1121,44 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
         misses |= uint64_t(cls[j] == kClsMiss) << (8 * j);
     }
     static_assert(kClassifyChunks <= 8, "one byte per run in `misses`");
-    // (not unrolled: the environment lookup is a lot of code, and its registers would halve the occupancy)
+    // the rays that left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
+    if (sc.envmap.type == PT_ENV_NONE) {
+        // (nothing to add: radiance so far is the sample)
 #pragma unroll 1
-    for (uint32_t j = 0; j < kClassifyChunks; j++) {
-        if ((misses >> (8 * j)) & 1u) {
-            // the ray left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
-            const uint32_t slot = slot0 + j * kClassifyBlock;
-            const float4 rad_p = pool.rad_p[slot];
-            V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
-            if (sc.envmap.type != PT_ENV_NONE) {
-                const float4 thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
-                radiance = radiance + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
+        for (uint32_t j = 0; j < kClassifyChunks; j++) {
+            if ((misses >> (8 * j)) & 1u) {
+                const float4 rad_p = pool.rad_p[slot0 + j * kClassifyBlock];
+                float* p = samples + 3 * size_t(fbits(rad_p.w));
+                p[0] = rad_p.x;
+                p[1] = rad_p.y;
+                p[2] = rad_p.z;
             }
-            float* p = samples + 3 * size_t(fbits(rad_p.w));
-            p[0] = radiance.x;
-            p[1] = radiance.y;
-            p[2] = radiance.z;
         }
+        return;
+    }
+    // The environment's value is a few hundred instructions (two inverse trigonometric functions in double
+    // precision, a texture lookup), and a quarter of the records or fewer are misses: each wave first collects its
+    // misses in LDS and then works them off with all lanes.
+    __shared__ uint32_t missSlots[kWaves][kClassifyChunks * 64u];
+    uint32_t nMisses = 0; // of the wave (the same in every lane)
+#pragma unroll
+    for (uint32_t j = 0; j < kClassifyChunks; j++) {
+        const bool mine = (misses >> (8 * j)) & 1u;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+        if (mine)
+            missSlots[wave][nMisses + uint32_t(__popcll(m & below))] = slot0 + j * kClassifyBlock;
+        nMisses += uint32_t(__popcll(m));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the entries are read by other lanes of the wave
+#pragma unroll 1
+    for (uint32_t i = lane; i < nMisses; i += 64u) {
+        const uint32_t slot = missSlots[wave][i];
+        const float4 rad_p = pool.rad_p[slot], thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
+        const V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z) + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
+        float* p = samples + 3 * size_t(fbits(rad_p.w));
+        p[0] = radiance.x;
+        p[1] = radiance.y;
+        p[2] = radiance.z;
     }
 }
 
