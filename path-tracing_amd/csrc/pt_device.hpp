@@ -605,9 +605,11 @@ PT_DEV bool surfaceTest(const DevScene& sc, const float4* __restrict__ surf, uin
 // One step of that walk: test node `cur`, test its surface if it is a leaf whose
 // box is hit, and move `cur` on.  The walk is over when cur >= sc.n_nodes.
 // `nodes` and `surf` are the node and surface tables (in HBM, or a copy in LDS).
+// `boxAmin` (>= amin): boxes that the ray leaves before this distance are skipped as well -- for a caller who knows
+// that no surface is hit before it (see traceRetryKernel); the reference's walk has boxAmin = amin.
 template <bool COUNT, bool DYN>
 PT_DEV void traverseStep(const DevScene& sc, const float4* __restrict__ nodes, const float4* __restrict__ surf,
-                         const Ray& ray, float amin, float& amax, uint32_t& cur, HitLite& best, Counters* cnt)
+                         const Ray& ray, float amin, float boxAmin, float& amax, uint32_t& cur, HitLite& best, Counters* cnt)
 {
     float4 n0 = nodes[2 * cur + 0];
     float4 n1 = nodes[2 * cur + 1];
@@ -615,7 +617,7 @@ PT_DEV void traverseStep(const DevScene& sc, const float4* __restrict__ nodes, c
     uint32_t leaf = fbits(n1.w);
     if (COUNT)
         cnt->nodeVisits++;
-    if (aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax)) {
+    if (aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, boxAmin, amax)) {
         if (!(leaf & kInnerBit)) {
             if (COUNT)
                 cnt->leafTests++;
@@ -664,7 +666,7 @@ PT_DEV HitLite noHit()
 }
 
 template <bool COUNT, bool DYN = true>
-PT_DEV HitLite closestHit(const DevScene& sc, const Ray& ray, float amin, float amax, Counters* cnt)
+PT_DEV HitLite closestHitFrom(const DevScene& sc, const Ray& ray, float amin, float boxAmin, float amax, Counters* cnt)
 {
     HitLite best = noHit();
     if (COUNT)
@@ -672,8 +674,14 @@ PT_DEV HitLite closestHit(const DevScene& sc, const Ray& ray, float amin, float 
     uint32_t cur = 0;
     const uint32_t end = sc.n_nodes;
     while (cur < end)
-        traverseStep<COUNT, DYN>(sc, sc.nodes, sc.surf, ray, amin, amax, cur, best, cnt);
+        traverseStep<COUNT, DYN>(sc, sc.nodes, sc.surf, ray, amin, boxAmin, amax, cur, best, cnt);
     return best;
+}
+
+template <bool COUNT, bool DYN = true>
+PT_DEV HitLite closestHit(const DevScene& sc, const Ray& ray, float amin, float amax, Counters* cnt)
+{
+    return closestHitFrom<COUNT, DYN>(sc, ray, amin, amin, amax, cnt);
 }
 
 // The full HitRecord of reference src/15/surface.hpp:9-30

@@ -50,6 +50,10 @@ constexpr uint32_t kDestIsSample = 0x80000000u;
 constexpr uint32_t kBackEmits = 0x40000000u;
 constexpr uint32_t kLightMask = 0x3FFFFFFFu;
 constexpr uint32_t kRetryIsShadow = 0x80000000u; // retry list entry: a shadow-queue entry rather than a slot
+constexpr uint32_t kRetryFullWalk = 0x80000000u; // second word of the entry: the bound itself, not the closest distance
+#ifndef PT_RETRY_PRUNE
+#define PT_RETRY_PRUNE 1
+#endif
 
 struct Pool {
     float4* o_t;   // ray origin, time
@@ -898,8 +902,17 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     float bound = best.sid != PT_NO_HIT ? cull * (1.0f + kTieBand) : kFltMax;
                     if (!(bound < kFltMax))
                         bound = kFltMax;
+                    // Usually the limit is the closest distance found times the band (the boxes above that surface
+                    // are entered before it) and no subtree was left out: then the entry carries that distance, from
+                    // which the second pass works out the same bound and also where its search may begin (see
+                    // traceRetryKernel); otherwise it carries the bound, marked by the sign bit.
+                    uint32_t word = fbits(bound) | kRetryFullWalk;
+#if PT_RETRY_PRUNE
+                    if (best.sid != PT_NO_HIT && !(dropGate <= cull) && cull == best.a * (1.0f + kTieBand) && cull < kFltMax)
+                        word = fbits(best.a);
+#endif
                     retryBuf[threadIdx.x >> 6][nRetry + uint32_t(__popcll(am & below))]
-                        = make_uint2(shadow ? (kRetryIsShadow | (item)) : item, fbits(bound));
+                        = make_uint2(shadow ? (kRetryIsShadow | (item)) : item, word);
                 }
                 nRetry += uint32_t(__popcll(am));
                 if (STATS && ambiguous)
@@ -958,11 +971,22 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
     for (uint32_t i = (blockIdx.x / kRetryShards) * 256u + threadIdx.x; i < n; i += (gridDim.x / kRetryShards) * 256u) {
         const uint2 entry = pool.retry[size_t(list) * pool.retryCap + i];
         const uint32_t e = entry.x;
-        const float bound = __uint_as_float(entry.y);
+        // The first pass visited every subtree entered within its limit and found nothing closer than its closest
+        // distance a: a box that the ray leaves before a * (1 - 2 bands) holds no surface that is hit (a surface's
+        // distance and the exit distance of a box around it differ by rounding, which the band covers as it does on
+        // the entry side), so the walk may skip it -- most of the boxes between the ray's origin and the hit.
+        float bound = __uint_as_float(entry.y & ~kRetryFullWalk), boxAmin = 0.0001f;
+        if (!(entry.y & kRetryFullWalk)) {
+            const float a = bound;
+            bound = a * (1.0f + kTieBand) * (1.0f + kTieBand);
+            if (!(bound < kFltMax))
+                bound = kFltMax;
+            boxAmin = fmaxf(a * (1.0f - 2.0f * kTieBand), 0.0001f);
+        }
         if (!(e & kRetryIsShadow)) {
             const float4 o_t = pool.o_t[e], d_s = pool.d_s[e];
             const Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
-            const HitLite best = closestHit<STATS, DYN>(sc, ray, 0.0001f, bound, &cnt);
+            const HitLite best = closestHitFrom<STATS, DYN>(sc, ray, 0.0001f, boxAmin, bound, &cnt);
             pool.hit[e] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                      fbits(best.a), fbits(best.u), fbits(best.v));
             pool.cls[e] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
@@ -981,7 +1005,7 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
                 destW = fbits(r.w);
             }
             const Ray ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
-            const HitLite best = closestHit<STATS, DYN>(sc, ray, 0.0001f, bound, &cnt);
+            const HitLite best = closestHitFrom<STATS, DYN>(sc, ray, 0.0001f, boxAmin, bound, &cnt);
             shadowArrive<DYN>(sc, sc.surf, pool, samples, q, ray, best, payload, dest, destW, destValue);
         }
     }
