@@ -26,4 +26,4 @@ with pt.DeviceScene(scene) as dev:
     samples = (W // 2) * (H // 2) * 16
     print(name, "rays/sample %.2f (path %.2f, shadow %.2f); per ray:" % (
         rays / samples, c.get("path_rays", 0) / samples, c.get("shadow_rays", 0) / samples),
-        {k: round(v / rays, 2) for k, v in c.items() if v and k not in ("path_rays", "shadow_rays")})
+        {k: round(v / rays, 5) for k, v in c.items() if v and k not in ("path_rays", "shadow_rays")})
