@@ -394,6 +394,9 @@ typedef struct pt_walk_counters {
     uint64_t retry_rays;           /* rays handed to the storage-order second pass */
     uint64_t retry_node_visits;    /* its node visits, 32 bytes each */
     uint64_t retry_surface_tests;  /* its surface tests, 48 bytes each */
+    uint64_t null_shadow_rays;     /* shadow rays of the reference algorithm that were not traced: the light-pdf test
+                                      of the chosen light had already shown that they could add nothing but zeros
+                                      (they miss the light, or arrive at a side that does not emit) */
 } pt_walk_counters;
 
 int pt_scene_count_walk(pt_scene* scene, int enable);

@@ -116,7 +116,8 @@ PT_SHARD_TILES, PT_SHARD_SAMPLES = 0, 1
 class pt_walk_counters(C.Structure):
     _fields_ = [("path_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("box_rows", C.c_uint64),
                 ("leaf_rows", C.c_uint64), ("surface_tests", C.c_uint64), ("retry_rays", C.c_uint64),
-                ("retry_node_visits", C.c_uint64), ("retry_surface_tests", C.c_uint64)]
+                ("retry_node_visits", C.c_uint64), ("retry_surface_tests", C.c_uint64),
+                ("null_shadow_rays", C.c_uint64)]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}
@@ -126,5 +127,5 @@ EXPECTED_SIZES = {
     "pt_transform": 40, "pt_animation": 88, "pt_texture": 48, "pt_material": 48, "pt_mesh": 40,
     "pt_sphere": 24, "pt_surface": 16, "pt_bvh_node": 32, "pt_envmap": 32, "pt_scene_desc": 240,
     "pt_camera": 116, "pt_render_params": 64, "pt_hit": 16, "pt_counters": 56, "pt_kernel_time": 40,
-    "pt_walk_counters": 64,
+    "pt_walk_counters": 72,
 }

@@ -1145,6 +1145,7 @@ PT_DEV float powerHeuristicMIS(float f, float g) // reference src/15/pathtracer.
 struct PathParams {
     int maxSegments;
     int rrStart;
+    int traceNullShadowRays = 0; // trace the shadow rays that are known to add nothing, as the reference does
 };
 
 // mean of Surface::p over all lights (reference src/15/pathtracer.cpp:78-81,88-91)
@@ -1162,10 +1163,16 @@ __device__ inline float lightsPdf(const DevScene& sc, V3 origin, V3 dir, float t
 // The same for two directions from one point at once (the scattered direction and the direction to the
 // sampled light, reference src/15/pathtracer.cpp:78-81 and 88-91): every light is read once, and what depends
 // on the light alone (edges, normal, area) is computed once.  Each direction sees the arithmetic of surfaceP.
-__device__ inline void lightsPdf2(const DevScene& sc, V3 origin, V3 dirA, V3 dirB, float time, float& pA, float& pB)
+// `chosen` = the light that dirB was sampled on.  `chosenSide` tells what the test of that very surface with the ray
+// along dirB says, which is the test a shadow ray along dirB makes at that surface's leaf: kSideMiss (the ray cannot
+// arrive at it), kSideFront, kSideBack, or kSideUnknown for a light that is no triangle.
+enum : uint32_t { kSideUnknown = 0, kSideMiss, kSideFront, kSideBack };
+__device__ inline void lightsPdf2(const DevScene& sc, V3 origin, V3 dirA, V3 dirB, float time, uint32_t chosen, float& pA,
+                                  float& pB, uint32_t& chosenSide)
 {
     const Ray ra = makeRay(origin, dirA, time), rb = makeRay(origin, dirB, time);
     float sumA = 0.0f, sumB = 0.0f;
+    chosenSide = kSideUnknown;
     for (uint32_t i = 0; i < sc.n_lights; i++) {
         const uint32_t sid = sc.lights[i];
         const float4 r0 = sc.surf[3 * size_t(sid) + 0];
@@ -1176,6 +1183,8 @@ __device__ inline void lightsPdf2(const DevScene& sc, V3 origin, V3 dirA, V3 dir
             bool bs;
             const bool hitA = triTest(A, B, C, ra, 0.0f, kFltMax, aA, u, v, bs);
             const bool hitB = triTest(A, B, C, rb, 0.0f, kFltMax, aB, u, v, bs);
+            if (i == chosen)
+                chosenSide = !hitB ? kSideMiss : bs ? kSideBack : kSideFront;
             float valA = 0.0f, valB = 0.0f;
             if (hitA || hitB) {
                 const V3 edgeCross = cross(B - A, C - A);

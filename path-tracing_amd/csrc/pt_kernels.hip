@@ -340,6 +340,7 @@ int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_
     a.s1 = s1;
     a.pp.maxSegments = p->max_path_segments > 0 ? p->max_path_segments : 128;
     a.pp.rrStart = p->rr_start_segment == 0 ? 5 : (p->rr_start_segment < 0 ? 0 : p->rr_start_segment);
+    a.pp.traceNullShadowRays = std::getenv("PT_TRACE_NULL_SHADOW_RAYS") != nullptr;
     return PT_OK;
 }
 

@@ -344,6 +344,7 @@ enum : uint32_t {
     kStatRetryRays,    // rays handed to the storage-order second pass
     kStatRetryNodes,   //   its node visits (32 bytes each)
     kStatRetrySurfaceTests,
+    kStatNullShadowRays, // shadow rays the shading kernel did not queue because they could only add zeros
     kStatWords
 };
 
@@ -1191,7 +1192,8 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
                                                                        uint32_t* __restrict__ counters, int parity,
                                                                        float* __restrict__ samples, uint32_t shadowCap,
-                                                                       FastDiv blocksPerShard)
+                                                                       FastDiv blocksPerShard,
+                                                                       unsigned long long* __restrict__ stats)
 {
     __shared__ uint32_t lds[2 * (kShadeBlock / 64 + 1)];
     // the block's entries lie inside one shard's list
@@ -1204,7 +1206,7 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
     const bool valid = entry < fill;
     const uint32_t slot = valid ? pool.hitList[size_t(shard) * pool.listCap + entry] : 0u;
     bool finished = false;
-    bool haveShadow = false;
+    bool haveShadow = false, nullShadow = false;
     V3 shOrigin, shDir, shC, shBack = v3(0.0f);
     float shTime = 0.0f;
     uint32_t shLight = 0;
@@ -1252,7 +1254,8 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
                 V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
                 // (the two sums over the lights draw no random numbers, so they can be taken together)
                 float lightsP, lightDirP;
-                lightsPdf2(sc, hr.position, sr.direction, lightDir, ray.time, lightsP, lightDirP);
+                uint32_t lightSide;
+                lightsPdf2(sc, hr.position, sr.direction, lightDir, ray.time, lightIndex, lightsP, lightDirP, lightSide);
                 nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
                 if (lightDirP > 0.0f) {
                     // (a two-sided material scattered as one of its sides and answers scatterToDirection itself)
@@ -1282,6 +1285,17 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
                         if (shBack.x != 0.0f || shBack.y != 0.0f || shBack.z != 0.0f)
                             shLight |= kBackEmits;
                         shC = shC * materialLe(sc, lmat, false);
+                        // A shadow ray adds its contribution if its closest hit is the chosen light, by the side it
+                        // arrives at.  The test it would make at that light's leaf has just been made for the light's
+                        // pdf (same ray, same vertices, a wider interval): if that missed, or found the side whose
+                        // contribution is zero, the ray can add nothing but zeros and is not traced.
+                        // (PT_TRACE_NULL_SHADOW_RAYS traces them all the same: the tracing kernels then do exactly
+                        // the reference's work.)
+                        const bool frontNull = shC.x == 0.0f && shC.y == 0.0f && shC.z == 0.0f;
+                        const bool backNull = !(shLight & kBackEmits);
+                        nullShadow = !pp.traceNullShadowRays
+                            && (lightSide == kSideMiss || (lightSide == kSideFront && frontNull) || (lightSide == kSideBack && backNull));
+                        haveShadow = !nullShadow;
                     }
                 }
             }
@@ -1316,6 +1330,11 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
         }
     }
 
+    if (stats) { // (instrumented renders only; the same for the whole launch)
+        const uint32_t n = uint32_t(__popcll(__builtin_amdgcn_ballot_w64(nullShadow)));
+        if (laneId() == 0 && n)
+            atomicAdd(&stats[kStatNullShadowRays], (unsigned long long)n);
+    }
     // two reservations with one atomic per block each: a place in the shard's shadow-ray queue,
     // and the next free place in the shard's region of the other pool for every path that goes on
     const bool goesOn = valid && !finished;
@@ -1741,7 +1760,8 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
             hipLaunchKernelGGL(shadeHitsKernel, dim3(shadeBlocks * kShards), dim3(kShadeBlock), 0, stream, sc->dev, cur, next, a.pp,
-                               w.counters, parity, w.samples, shadowCap, FastDiv(shadeBlocks));
+                               w.counters, parity, w.samples, shadowCap, FastDiv(shadeBlocks),
+                               sc->walkStatsOn ? w.walkStats : nullptr);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kGenerate, stream);
             hipLaunchKernelGGL(generateKernel, dim3(generateBlocks * kShards), block, 0, stream, sc->dev, next, a, b, w.counters,

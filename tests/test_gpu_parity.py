@@ -237,43 +237,48 @@ def test_kernel_times_are_recorded(cornell):
 
 
 def test_walk_counters_of_the_executed_walk(cornell, oracle):
-    """The instrumented tracing kernels: in storage order (scene in LDS, or PT_TRAVERSAL=reference) the executed
-    walk is the reference's, so its sums equal the work counters of the reference algorithm -- except that camera
-    rays missing the root box are finished by the generating kernel (one ray and one node visit each, never
-    traced); the nearer-child-first walk fetches fewer rows; the image is the same with and without counting."""
+    """The instrumented tracing kernels.  With every shadow ray traced (PT_TRACE_NULL_SHADOW_RAYS) the walk in
+    storage order (scene in LDS, or PT_TRAVERSAL=reference) is the reference's, so its sums equal the work counters
+    of the reference algorithm -- except that camera rays missing the root box are finished by the generating kernel
+    (one ray and one node visit each, never traced).  By default the shading kernel leaves out the shadow rays that
+    can only add zeros (they arrive at the light's dark side): fewer rays, rows and tests, counted, same image.  The
+    nearer-child-first walk fetches fewer rows; the image is the same with and without counting."""
     scene, cam, dev = cornell
     p = pt.make_params(64, 48, 3)
     want, wcnt = oracle.render(scene.ptr, cam, p, math_mode=1, counters=True)
     ref = wcnt.as_dict()
 
-    def counted():
-        dev.count_walk(True)
-        img = dev.render(cam, p)
-        c = dev.walk_counters()
-        dev.count_walk(False)
-        assert same_bits(img, want)
-        return c
-
-    for env in ({}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}):
+    def counted(**env):
         os.environ.update(env)
         try:
-            c = counted()
+            dev.count_walk(True)
+            img = dev.render(cam, p)
+            c = dev.walk_counters()
+            dev.count_walk(False)
         finally:
             for k in env:
                 del os.environ[k]
+        assert same_bits(img, want)
+        return c
+
+    root_misses = None
+    for env in ({}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}):
+        c = counted(PT_TRACE_NULL_SHADOW_RAYS="1", **env)
         root_misses = ref["rays"] - (c["path_rays"] + c["shadow_rays"])
         assert 0 <= root_misses <= 64 * 48 * 9
         assert c["box_rows"] + root_misses == ref["node_visits"], env
         assert c["surface_tests"] == ref["leaf_tests"], env
-        assert c["retry_rays"] == 0 and c["leaf_rows"] == 0
-    os.environ["PT_NO_LDS_SCENE"] = "1"
-    try:
-        c = counted()
-    finally:
-        del os.environ["PT_NO_LDS_SCENE"]
+        assert c["retry_rays"] == 0 and c["leaf_rows"] == 0 and c["null_shadow_rays"] == 0
+        d = counted(**env)
+        assert d["path_rays"] == c["path_rays"]
+        assert d["null_shadow_rays"] > 0 and d["shadow_rays"] + d["null_shadow_rays"] == c["shadow_rays"], env
+        assert d["box_rows"] < c["box_rows"] and d["surface_tests"] < c["surface_tests"]
+    c = counted(PT_NO_LDS_SCENE="1", PT_TRACE_NULL_SHADOW_RAYS="1")
     assert c["path_rays"] + c["shadow_rays"] + root_misses == ref["rays"]
     assert 0 < c["box_rows"] < ref["node_visits"]
     assert c["retry_node_visits"] >= c["retry_rays"]
+    c = counted(PT_NO_LDS_SCENE="1")
+    assert c["path_rays"] + c["shadow_rays"] + c["null_shadow_rays"] + root_misses == ref["rays"]
     # switched off: the sums stay where they are
     dev.render(cam, p)
     assert dev.walk_counters() == c
