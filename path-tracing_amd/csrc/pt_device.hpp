@@ -654,6 +654,33 @@ PT_DEV void nodeStep(const float4* __restrict__ nodes, const Ray& ray, float ami
     cur = (hit && inner) ? cur + 1 : escape;
 }
 
+// The same step on a copy of the node table whose two link words are packed for this walk (see packNodeLinks):
+// `cur` alone then says what a lane does next -- below the node count: walk; kLeafDue set: the surface in `leafWord`
+// is due for its test (cur & ~kLeafDue = where the walk goes on afterwards); anything else: the walk is over.
+constexpr uint32_t kLeafDue = 0x80000000u;
+constexpr uint32_t kNoWalk = 0x7FFFFFFFu; // a lane without a ray
+
+// word 6: escape link (low 16 bits) | surface id + 1 of a leaf (high 16 bits); word 7: where a lane goes when the
+// box is hit: the first child of an inner node, kLeafDue | escape link of a leaf.  Needs node and surface counts
+// below 2^16, which holds for every table that fits LDS.
+PT_DEV void packNodeLinks(uint32_t node, float4& n1)
+{
+    const uint32_t escape = fbits(n1.z), leaf = fbits(n1.w);
+    const bool inner = (leaf & kInnerBit) != 0;
+    n1.z = __uint_as_float(escape | (inner ? 0u : (leaf + 1u) << 16));
+    n1.w = __uint_as_float(inner ? node + 1u : (kLeafDue | escape));
+}
+
+PT_DEV void nodeStepPacked(const float4* __restrict__ nodes, const Ray& ray, float amin, float amax, uint32_t& cur,
+                           uint32_t& leafWord)
+{
+    const float4 n0 = nodes[2 * cur + 0];
+    const float4 n1 = nodes[2 * cur + 1];
+    const bool hit = aabbHit(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, amin, amax);
+    leafWord = fbits(n1.z);
+    cur = hit ? fbits(n1.w) : (fbits(n1.z) & 0xFFFFu);
+}
+
 PT_DEV HitLite noHit()
 {
     HitLite h;

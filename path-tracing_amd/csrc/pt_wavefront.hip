@@ -405,8 +405,12 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     }
     if (LDS) {
         const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
-        for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK)
-            ldsGeo[i] = sc.nodes[i];
+        for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK) {
+            float4 v = sc.nodes[i];
+            if (i & 1u)
+                packNodeLinks(i >> 1, v);
+            ldsGeo[i] = v;
+        }
         for (uint32_t i = threadIdx.x; i < nSurf4; i += BLOCK)
             ldsGeo[nNode4 + i] = sc.surf[i];
         if (DYN) {
@@ -441,8 +445,11 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     uint32_t item = 0;
     Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
     float amax = 0.0f;
-    uint32_t cur = 0;
-    uint32_t pending = kInner; // leaf surface whose box was hit and whose test is due
+    // Tables in LDS: the links are packed (packNodeLinks) and `cur` carries the lane's state (nodeStepPacked), so
+    // that "does this lane walk" is one comparison.  Tables in memory: `pending` = the leaf surface whose box was
+    // hit and whose test is due.
+    uint32_t cur = LDS ? kNoWalk : 0u;
+    uint32_t pending = kInner;
     HitLite best = noHit();
     // shadow rays: what to add on arrival, where, and the current value there
     float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -509,7 +516,31 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
         }
         // walk: node steps for every lane that still has nodes to visit and no surface waiting,
         // repeated while enough lanes are walking; then the waiting surfaces are tested together
-        {
+        if (LDS) {
+            uint64_t walkers = __builtin_amdgcn_ballot_w64(cur < sc.n_nodes);
+            while (walkers != 0) {
+                if (cur < sc.n_nodes) {
+                    nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
+                    if (STATS)
+                        nRows++;
+                }
+                if (cur < sc.n_nodes) {
+                    nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
+                    if (STATS)
+                        nRows++;
+                }
+                walkers = __builtin_amdgcn_ballot_w64(cur < sc.n_nodes);
+                if (__builtin_popcountll(walkers) < int(kWalkLanes))
+                    break;
+            }
+            if (cur & kLeafDue) {
+                if (surfaceTest<DYN>(sc, surf, anims, (pending >> 16) - 1u, ray, 0.0001f, amax, best))
+                    amax = best.a;
+                cur &= ~kLeafDue;
+                if (STATS)
+                    nTests++;
+            }
+        } else {
             bool walking = have && pending == kInner && cur < sc.n_nodes;
             while (__builtin_amdgcn_ballot_w64(walking) != 0) {
                 if (walking) {
@@ -528,16 +559,18 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                 if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanes)
                     break;
             }
-        }
-        if (have && pending != kInner) {
-            if (surfaceTest<DYN>(sc, surf, anims, pending, ray, 0.0001f, amax, best))
-                amax = best.a;
-            pending = kInner;
-            if (STATS)
-                nTests++;
+            if (have && pending != kInner) {
+                if (surfaceTest<DYN>(sc, surf, anims, pending, ray, 0.0001f, amax, best))
+                    amax = best.a;
+                pending = kInner;
+                if (STATS)
+                    nTests++;
+            }
         }
         if (have && cur >= sc.n_nodes) {
             have = false;
+            if (LDS)
+                cur = kNoWalk;
             if (!shadow) {
                 pool.hit[item] = make_uint4(best.sid == PT_NO_HIT ? PT_NO_HIT : (best.sid | (best.backside ? 0x80000000u : 0u)),
                                             fbits(best.a), fbits(best.u), fbits(best.v));
