@@ -365,7 +365,9 @@ PT_DEV void addStats(unsigned long long* __restrict__ stats, uint32_t which, uin
 // BLOCK = threads per block: 256, or one wave where the scene's tables are small enough for 32 blocks per compute
 // unit to hold their own copy in LDS (a block keeps its LDS until its slowest wave is through: one-wave blocks
 // measured 2 % faster on the Cornell box, and 30 % slower with the 12.5 KB of the 100 spheres).
-template <bool DYN, bool LDS, bool STATS, uint32_t BLOCK>
+// OCT: the node table in LDS holds a copy per combination of direction signs (nodeStepOctant); for static scenes of
+// a few dozen nodes, whose eight-fold table still leaves room for eight blocks per compute unit.
+template <bool DYN, bool LDS, bool STATS, uint32_t BLOCK, bool OCT = false>
 __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                    float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
                                                    int taken, unsigned long long* __restrict__ stats)
@@ -404,12 +406,26 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
             return;
     }
     if (LDS) {
-        const uint32_t nNode4 = 2u * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
-        for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK) {
-            float4 v = sc.nodes[i];
-            if (i & 1u)
-                packNodeLinks(i >> 1, v);
-            ldsGeo[i] = v;
+        static_assert(!OCT || (LDS && !DYN), "copies per direction sign: static scenes in LDS only");
+        const uint32_t nNode4 = (OCT ? kOctantRow4 : 2u) * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
+        if (OCT) {
+            for (uint32_t node = threadIdx.x; node < sc.n_nodes; node += BLOCK) {
+                const float4 n0 = sc.nodes[2u * node], n1 = sc.nodes[2u * node + 1u];
+#pragma unroll
+                for (uint32_t octant = 0; octant < 8u; octant++) {
+                    float4 r0, r1;
+                    octantRow(node, octant, n0, n1, r0, r1);
+                    ldsGeo[2u * (octant * sc.n_nodes + node)] = r0;
+                    ldsGeo[2u * (octant * sc.n_nodes + node) + 1u] = r1;
+                }
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK) {
+                float4 v = sc.nodes[i];
+                if (i & 1u)
+                    packNodeLinks(i >> 1, v);
+                ldsGeo[i] = v;
+            }
         }
         for (uint32_t i = threadIdx.x; i < nSurf4; i += BLOCK)
             ldsGeo[nNode4 + i] = sc.surf[i];
@@ -450,6 +466,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     // hit and whose test is due.
     uint32_t cur = LDS ? kNoWalk : 0u;
     uint32_t pending = kInner;
+    const float4* rows = nodes; // OCT: the ray's copy of the node table
     HitLite best = noHit();
     // shadow rays: what to add on arrival, where, and the current value there
     float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -502,6 +519,8 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                     have = true;
                 }
                 if (have) {
+                    if (OCT)
+                        rows = nodes + 2u * sc.n_nodes * octantOf(ray);
                     amax = kFltMax;
                     cur = 0;
                     pending = kInner;
@@ -520,12 +539,18 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
             uint64_t walkers = __builtin_amdgcn_ballot_w64(cur < sc.n_nodes);
             while (walkers != 0) {
                 if (cur < sc.n_nodes) {
-                    nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
+                    if (OCT)
+                        nodeStepOctant(rows, ray, 0.0001f, amax, cur, pending);
+                    else
+                        nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
                     if (STATS)
                         nRows++;
                 }
                 if (cur < sc.n_nodes) {
-                    nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
+                    if (OCT)
+                        nodeStepOctant(rows, ray, 0.0001f, amax, cur, pending);
+                    else
+                        nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
                     if (STATS)
                         nRows++;
                 }
@@ -1668,6 +1693,12 @@ int ensureBuffers(pt_scene* sc, uint32_t nSlots, uint64_t nSamples, uint64_t npi
 // too, and all three may take twice as much
 constexpr size_t kLdsGeoLimit = 16 * 1024;
 
+#ifndef PT_OCTANT_BLOCK
+#define PT_OCTANT_BLOCK 256
+#endif
+constexpr uint32_t kOctantBlock = PT_OCTANT_BLOCK;
+constexpr size_t kOctantLdsLimit = 20 * 1024; // eight blocks per compute unit
+
 // bytes of LDS that the tables of a scene traced from LDS take
 size_t ldsTableBytes(const pt_scene* sc)
 {
@@ -1720,6 +1751,18 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         // than filled lanes across runs: 882 against 959 us on the Cornell box); moving surfaces: runs taken from
         // counters by as many waves as the chip holds (601 against 667 us on the 100 moving spheres) -- eight per
         // SIMD, fewer when the scene's tables leave room for fewer blocks in LDS.  PT_TRACE_RUNS=fixed|taken overrides.
+        // The smallest static scenes: a copy of every node per combination of direction signs, in blocks of
+        // kOctantBlock threads that share the eight-fold table (PT_NO_OCTANT_ROWS: the plain table).
+        const size_t octLds = (size_t(kOctantRow4) * sc->dev.n_nodes + size_t(3) * sc->dev.n_surfaces) * 16;
+        if (LDS && !DYN && octLds <= kOctantLdsLimit && std::getenv("PT_NO_OCTANT_ROWS") == nullptr) {
+            const uint32_t blocks = (slotWaves + shadowWaves) / (kOctantBlock / 64u);
+            const uint32_t heldOct = uint32_t(sc->computeUnits) * std::min<uint32_t>(32u / (kOctantBlock / 64u), uint32_t((160u * 1024u) / octLds));
+            const bool takenOct = takenRuns && heldOct < blocks;
+            hipLaunchKernelGGL((traceKernel<false, LDS && !DYN, STATS, kOctantBlock, LDS && !DYN>), dim3(takenOct ? heldOct : blocks), dim3(kOctantBlock),
+                               octLds, stream, sc->dev, pool, w.counters, parity, w.samples, shadowCap, slotWaves, takenOct ? 1 : 0, stats);
+            sc->kt.end(stream);
+            return;
+        }
         const bool waveBlocks = LDS && !DYN && lds * 32u <= 160u * 1024u;
         const uint32_t wavesPerBlock = waveBlocks ? 1u : 4u, allBlocks = (slotWaves + shadowWaves) / wavesPerBlock;
         const uint32_t perCu = std::max<uint32_t>(1u, lds ? std::min<uint32_t>(32u / wavesPerBlock, uint32_t((160u * 1024u) / lds))
