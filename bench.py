@@ -420,8 +420,13 @@ def main():
             "config": {"workload": label, "width": W, "height": H, "spp": spp, "bvh": args.bvh, "bvh_build_ms": bvh_build_ms,
                        "samples_per_step": total_samples / args.steps,
                        "sharding": "single GPU" if world == 1 else shard_text},
+            # rays of the reference algorithm settled per second, and those of them that a tracing kernel walks: camera
+            # rays that miss the box of the whole scene and shadow rays that can only add zeros are settled without
             "rays_per_s": value * ref_per_sample["rays"],
-            "rmse": rmse_against_converged(image, extra.get("converged"), spp) if not args.sqrt_spp else None,
+            "traced_rays_per_s": value * first_pass_rays,
+            # (an animation step on several GPUs leaves another frame in rank 0's buffer than the converged one)
+            "rmse": rmse_against_converged(image, extra.get("converged"), spp)
+                    if not args.sqrt_spp and not (frames and world > 1) else None,
             "roofline": roofline,
             "whole_step": whole,
             "kernels": kernels,

@@ -99,7 +99,7 @@ def test_frames_and_samples_plan_covers_every_sample_once():
 
 
 def test_converged_images_are_present_and_sane(golden_dir):
-    for name in ("cornell", "mesh1000", "textured"):
+    for name in ("cornell", "mesh1000", "textured", "frames"):
         z = np.load(os.path.join(golden_dir, "converged_%s_96x54.npz" % name))
         assert z["image"].shape == (54, 96, 3) and np.isfinite(z["image"]).all()
         assert 0 < float(z["noise_rmse"]) < 0.02 * max(float(z["image"].mean()), 0.05)
