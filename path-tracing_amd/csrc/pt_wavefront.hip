@@ -717,8 +717,10 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
     bool have = false;
     uint32_t item = 0;
     Ray ray = makeRay(v3(0.0f), v3(1.0f), 0.0f);
-    uint32_t link = 0, top = 0;
-    bool walkOver = true; // nothing left to visit
+    // `link` is also the lane's state: kInnerBit set -- it stands on an inner node; kNoLink -- nothing left to visit
+    // (or no ray); else a leaf whose test is due
+    constexpr uint32_t kNoLink = 0x7FFFFFFFu; // (as a leaf link this would be node 2^30 - 1: the builders stop below)
+    uint32_t link = kNoLink, top = 0;
     float gate = 0.0f, cull = kFltMax, otherT = kFltMax;
     float dropGate = __builtin_huge_valf(); // nearest entry distance of a subtree that found no room on the stack
     HitLite best = noHit();
@@ -800,13 +802,11 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     dropGate = __builtin_huge_valf();
                     top = 0;
                     // the root
-                    walkOver = true;
+                    link = kNoLink;
                     if (sc.n_nodes > 0) {
                         const float4 n0 = nodes[0], n1 = nodes[1];
-                        if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, gate)) {
-                            walkOver = false;
+                        if (aabbEntry(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), ray, 0.0001f, cull, gate))
                             link = (fbits(n1.w) & kInnerBit) ? kInnerBit : kLeafRowBit; // inner number 0, or node 0
-                        }
                     }
                 }
             }
@@ -815,9 +815,9 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
         // inner nodes: test both children, go to the nearer one that is hit, keep the other;
         // repeated while enough lanes stand on inner nodes
         {
-            bool walking = have && !walkOver && (link & kInnerBit);
-            while (__builtin_amdgcn_ballot_w64(walking) != 0) {
-                if (walking) {
+            uint64_t walkers = __builtin_amdgcn_ballot_w64(int32_t(link) < 0);
+            while (walkers != 0) {
+                if (int32_t(link) < 0) {
                     const uint32_t k = link & ~kInnerBit;
                     const uint4 q0 = wide[2 * k + 0], q1 = wide[2 * k + 1];
                     if (STATS)
@@ -851,29 +851,29 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                         gate = take1 ? g1 : g2;
                         link = take1 ? q1.z : q1.w;
                     } else {
-                        walkOver = true; // nothing below: take the next kept node
+                        link = kNoLink; // nothing below: take the next kept node
                     }
                 }
-                // a lane with nothing below pops the nearest kept node still within the limit
-                if (have && walkOver) {
+                // a lane with nothing below pops the nearest kept node still within the limit (a lane without a ray
+                // has nothing kept)
+                if (link == kNoLink) {
                     while (top > 0) {
                         top--;
                         const uint2 e = stack[top][threadIdx.x];
                         if (!(__uint_as_float(e.y) > cull)) {
                             link = e.x;
                             gate = __uint_as_float(e.y);
-                            walkOver = false;
                             break;
                         }
                     }
                 }
-                walking = have && !walkOver && (link & kInnerBit);
-                if (uint32_t(__popcll(__builtin_amdgcn_ballot_w64(walking))) < kWalkLanesOrdered)
+                walkers = __builtin_amdgcn_ballot_w64(int32_t(link) < 0);
+                if (__builtin_popcountll(walkers) < int(kWalkLanesOrdered))
                     break;
             }
         }
         // leaves: test the surface, then take the next kept node
-        if (have && !walkOver && !(link & kInnerBit)) {
+        if (link < kNoLink) {
             HitLite h;
             bool found = false;
             if (link & kLeafRowBit) {
@@ -933,21 +933,20 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                 }
 #endif
             }
-            walkOver = true;
+            link = kNoLink;
             while (top > 0) {
                 top--;
                 const uint2 e = stack[top][threadIdx.x];
                 if (!(__uint_as_float(e.y) > cull)) {
                     link = e.x;
                     gate = __uint_as_float(e.y);
-                    walkOver = false;
                     break;
                 }
             }
         }
         // rays that are through: ambiguous ones are collected per wave in LDS and go to the retry list
         // in bulk (whole wave takes part in the bookkeeping)
-        const bool through = have && walkOver;
+        const bool through = have && link == kNoLink;
         const bool ambiguous = through && ((best.sid != PT_NO_HIT && otherT <= cull) || dropGate <= cull);
         {
             const uint64_t am = __builtin_amdgcn_ballot_w64(ambiguous);
