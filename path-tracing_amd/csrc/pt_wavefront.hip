@@ -522,7 +522,11 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                     if (OCT)
                         rows = nodes + 2u * sc.n_nodes * octantOf(ray);
                     amax = kFltMax;
-                    cur = 0;
+                    // Tables in LDS: the walk begins at the root's first child.  The root's box is the merge of its
+                    // children's, and the slab arithmetic is monotone in the planes, so a ray that misses it misses
+                    // both children too: the same surfaces get tested, one box test fewer for every ray that hits it
+                    // (which is every ray that starts inside the scene).
+                    cur = LDS && sc.n_nodes > 1u ? 1u : 0u;
                     pending = kInner;
                     best = noHit();
                     if (STATS) {

@@ -240,7 +240,7 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
     """The instrumented tracing kernels.  With every shadow ray traced (PT_TRACE_NULL_SHADOW_RAYS) the walk in
     storage order (scene in LDS, or PT_TRAVERSAL=reference) is the reference's, so its sums equal the work counters
     of the reference algorithm -- except that camera rays missing the root box are finished by the generating kernel
-    (one ray and one node visit each, never traced).  By default the shading kernel leaves out the shadow rays that
+    (one ray and one node visit each, never traced), and that the walk from LDS starts below the root.  By default the shading kernel leaves out the shadow rays that
     can only add zeros (they arrive at the light's dark side): fewer rays, rows and tests, counted, same image.  The
     nearer-child-first walk fetches fewer rows; the image is the same with and without counting."""
     scene, cam, dev = cornell
@@ -266,7 +266,11 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
         c = counted(PT_TRACE_NULL_SHADOW_RAYS="1", **env)
         root_misses = ref["rays"] - (c["path_rays"] + c["shadow_rays"])
         assert 0 <= root_misses <= 64 * 48 * 9
-        assert c["box_rows"] + root_misses == ref["node_visits"], env
+        # (the walk from LDS does not test the root's box: a ray that misses it misses both children as well, which
+        # are two visits where the reference has one -- a handful of rays that leave the open box near its rim)
+        root_tests = 0 if env else c["path_rays"] + c["shadow_rays"]
+        extra = c["box_rows"] + root_misses + root_tests - ref["node_visits"]
+        assert extra % 2 == 0 and 0 <= extra <= (0 if env else 64), (env, extra)
         assert c["surface_tests"] == ref["leaf_tests"], env
         assert c["retry_rays"] == 0 and c["leaf_rows"] == 0 and c["null_shadow_rays"] == 0
         d = counted(**env)
