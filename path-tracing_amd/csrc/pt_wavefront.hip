@@ -239,6 +239,9 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
 #ifndef PT_WALK_LANES
 #define PT_WALK_LANES 16
 #endif
+#ifndef PT_STEPS_PER_VOTE
+#define PT_STEPS_PER_VOTE 4 // node steps of the LDS walk between two votes on going on
+#endif
 constexpr uint32_t kItemsPerLane = PT_ITEMS_PER_LANE;
 constexpr uint32_t kRefillLanes = PT_REFILL_LANES; // refill once this many lanes are idle
 #ifndef PT_REFILL_LANES_ORDERED
@@ -542,21 +545,16 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
         if (LDS) {
             uint64_t walkers = __builtin_amdgcn_ballot_w64(cur < sc.n_nodes);
             while (walkers != 0) {
-                if (cur < sc.n_nodes) {
-                    if (OCT)
-                        nodeStepOctant(rows, ray, 0.0001f, amax, cur, pending);
-                    else
-                        nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
-                    if (STATS)
-                        nRows++;
-                }
-                if (cur < sc.n_nodes) {
-                    if (OCT)
-                        nodeStepOctant(rows, ray, 0.0001f, amax, cur, pending);
-                    else
-                        nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
-                    if (STATS)
-                        nRows++;
+#pragma unroll
+                for (int k = 0; k < PT_STEPS_PER_VOTE; k++) {
+                    if (cur < sc.n_nodes) {
+                        if (OCT)
+                            nodeStepOctant(rows, ray, 0.0001f, amax, cur, pending);
+                        else
+                            nodeStepPacked(nodes, ray, 0.0001f, amax, cur, pending);
+                        if (STATS)
+                            nRows++;
+                    }
                 }
                 walkers = __builtin_amdgcn_ballot_w64(cur < sc.n_nodes);
                 if (__builtin_popcountll(walkers) < int(kWalkLanes))
@@ -672,6 +670,9 @@ PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx,
 
 #ifndef PT_ORDERED_WAVES
 #define PT_ORDERED_WAVES 6
+#endif
+#ifndef PT_ORDERED_STEPS_PER_VOTE
+#define PT_ORDERED_STEPS_PER_VOTE 2 // inner-node steps (each followed by the pops that became due) between two votes
 #endif
 #ifndef PT_ORDERED_BLOCK
 #define PT_ORDERED_BLOCK 256
@@ -821,6 +822,8 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
         {
             uint64_t walkers = __builtin_amdgcn_ballot_w64(int32_t(link) < 0);
             while (walkers != 0) {
+#pragma unroll
+                for (int rep = 0; rep < PT_ORDERED_STEPS_PER_VOTE; rep++) {
                 if (int32_t(link) < 0) {
                     const uint32_t k = link & ~kInnerBit;
                     const uint4 q0 = wide[2 * k + 0], q1 = wide[2 * k + 1];
@@ -870,6 +873,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                             break;
                         }
                     }
+                }
                 }
                 walkers = __builtin_amdgcn_ballot_w64(int32_t(link) < 0);
                 if (__builtin_popcountll(walkers) < int(kWalkLanesOrdered))
