@@ -78,6 +78,12 @@ struct DevScene {
     const DevMesh* meshes;
     const pt_sphere* spheres;
     const uint32_t* lights;
+    // Per surface, for a triangle with a fixed pose and no vertex normals (flag 64 in surfAttr): the unit normal of
+    // its plane, normalize(cross(B - A, C - A)) as the hit record and the light pdf compute it, and half the length of
+    // that cross product (its area) -- worked out once at upload with the same operations.  lightGeo repeats the row
+    // of light i (w < 0: not such a triangle).
+    const float4* faceN;
+    const float4* lightGeo;
     const pt_material* materials;
     const pt_texture* textures;
     const float* texels;
@@ -768,6 +774,41 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     hr.surface = h.sid;
     hr.position = rayAt(ray, h.a);
     const uint4 attr = sc.surfAttr[h.sid];
+    if ((attr.w >> 24) & 64u) {
+        // a triangle with a fixed pose and no vertex normals, of a mesh without animation: the normal of its plane
+        // was worked out at upload, the vertices are not needed
+        const uint32_t flags = attr.w >> 24;
+        const float4 fn = sc.faceN[h.sid];
+        V3 nrm = v3(fn.x, fn.y, fn.z);
+        if (h.backside)
+            nrm = -nrm;
+        const size_t i0 = attr.x, i1 = attr.y, i2 = attr.z;
+        const float u = h.u, v = h.v;
+        const float w = 1.0f - u - v;
+        V2 tc = V2{ 0.0f, 0.0f };
+        if ((flags & 2u) && (flags & 16u)) {
+            const float* a = sc.texcoords + 2 * i0;
+            const float* b = sc.texcoords + 2 * i1;
+            const float* c = sc.texcoords + 2 * i2;
+            tc = V2{ w * a[0] + u * b[0] + v * c[0], w * a[1] + u * b[1] + v * c[1] };
+        }
+        V3 tng = v3(0.0f);
+        if (flags & 32u) {
+            if (flags & 4u) {
+                tng = w * v3(sc.tangents + 3 * i0) + u * v3(sc.tangents + 3 * i1) + v * v3(sc.tangents + 3 * i2);
+                tng = tng - dot(nrm, tng) * nrm;
+                if (dot(tng, tng) > kEps)
+                    tng = normalize(tng);
+            }
+            tng = normalize(tng);
+        }
+        hr.normal = nrm;
+        hr.texcoord = tc;
+        hr.tangent = tng;
+        hr.backside = h.backside;
+        hr.material = int32_t(attr.w & 0xFFFFFFu);
+        return hr;
+    }
     float4 r0 = sc.surf[3 * size_t(h.sid) + 0];
     float4 r1 = sc.surf[3 * size_t(h.sid) + 1];
     uint32_t kind = fbits(r0.w);
@@ -1251,10 +1292,18 @@ __device__ inline void lightsPdf2(const DevScene& sc, V3 origin, V3 dirA, V3 dir
                 chosenSide = !hitB ? kSideMiss : bs ? kSideBack : kSideFront;
             float valA = 0.0f, valB = 0.0f;
             if (hitA || hitB) {
-                const V3 edgeCross = cross(B - A, C - A);
-                const float edgeCrossLength = ::sqrtf(dot(edgeCross, edgeCross));
-                const V3 faceNormal = edgeCross / edgeCrossLength;
-                const float faceArea = 0.5f * edgeCrossLength;
+                V3 faceNormal;
+                float faceArea;
+                const float4 lg = sc.lightGeo[i]; // (the same for every lane)
+                if (lg.w >= 0.0f) {
+                    faceNormal = v3(lg.x, lg.y, lg.z);
+                    faceArea = lg.w;
+                } else {
+                    const V3 edgeCross = cross(B - A, C - A);
+                    const float edgeCrossLength = ::sqrtf(dot(edgeCross, edgeCross));
+                    faceNormal = edgeCross / edgeCrossLength;
+                    faceArea = 0.5f * edgeCrossLength;
+                }
                 if (hitA)
                     valA = (aA * aA) / (fabs_(dot(faceNormal, -ra.direction)) * faceArea);
                 if (hitB)

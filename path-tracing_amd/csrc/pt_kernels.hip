@@ -472,6 +472,7 @@ try {
     bool hasDynamic = false;
     std::vector<float4> surf(3 * d->n_surfaces);
     std::vector<uint4> surfAttr(d->n_surfaces);
+    std::vector<float4> faceN(d->n_surfaces, make_float4(0.0f, 0.0f, 0.0f, -1.0f));
     if (d->n_materials >= (1u << 24))
         return fail(PT_ERR_LIMIT, "more than 2^24 materials");
     for (uint64_t i = 0; i < d->n_surfaces; i++) {
@@ -502,8 +503,17 @@ try {
                 return fail(PT_ERR_LIMIT, "more than 2^24 meshes");
             surf[3 * i + 1] = make_float4(B.x, B.y, B.z, bitsf(uint32_t(s.owner) | (matClassOf(m.material) << 24)));
             surf[3 * i + 2] = make_float4(C.x, C.y, C.z, bitsf(s.index));
-            const uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
+            uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
                 | (m.animation >= 0 ? 8u : 0u) | materialNeeds(m.material, 0);
+            if (kind == kTriStatic && !m.has_normals && m.animation < 0) {
+                // the normal of the triangle's plane and its area, with the operations of the hit record
+                // (reference src/15/surface_triangle.hpp:151-156) and of Surface::p (:201-204)
+                const V3 edgeCross = cross(B - A, C - A);
+                const float edgeCrossLength = ::sqrtf(dot(edgeCross, edgeCross));
+                const V3 n = edgeCross / edgeCrossLength;
+                faceN[i] = make_float4(n.x, n.y, n.z, 0.5f * edgeCrossLength);
+                flags |= 64u;
+            }
             surfAttr[i] = make_uint4(m.first_vertex + idx[0], m.first_vertex + idx[1], m.first_vertex + idx[2],
                                      uint32_t(m.material) | (flags << 24));
         } else {
@@ -563,6 +573,7 @@ try {
     float4* dSurf = nullptr;
     uint4* dSurfAttr = nullptr;
     float4* dMatConst = nullptr;
+    float4 *dFaceN = nullptr, *dLightGeo = nullptr;
     float *dPos = nullptr, *dNrm = nullptr, *dTc = nullptr, *dTng = nullptr, *dTexels = nullptr;
     uint32_t *dIdx = nullptr, *dLights = nullptr;
     DevMesh* dMeshes = nullptr;
@@ -580,6 +591,11 @@ try {
     if ((rc = upload(surf.data(), surf.size(), &dSurf, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(surfAttr.data(), surfAttr.size(), &dSurfAttr, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(matConst.data(), matConst.size(), &dMatConst, sc->owned)) != PT_OK) return bail(rc);
+    std::vector<float4> lightGeo(d->n_lights);
+    for (uint64_t i = 0; i < d->n_lights; i++)
+        lightGeo[i] = faceN[d->lights[i]];
+    if ((rc = upload(faceN.data(), faceN.size(), &dFaceN, sc->owned)) != PT_OK) return bail(rc);
+    if ((rc = upload(lightGeo.data(), lightGeo.size(), &dLightGeo, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->positions, 3 * d->n_vertices, &dPos, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->normals, 3 * d->n_vertices, &dNrm, sc->owned)) != PT_OK) return bail(rc);
     if ((rc = upload(d->texcoords, 2 * d->n_vertices, &dTc, sc->owned)) != PT_OK) return bail(rc);
@@ -607,6 +623,8 @@ try {
     dev.meshes = dMeshes;
     dev.spheres = dSpheres;
     dev.lights = dLights;
+    dev.faceN = dFaceN;
+    dev.lightGeo = dLightGeo;
     dev.materials = dMats;
     dev.textures = dTex;
     dev.texels = dTexels;
