@@ -288,6 +288,40 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
     assert dev.walk_counters() == c
 
 
+def test_tracing_kernel_variants_of_a_small_scene(golden_dir, oracle):
+    """The walks a small static scene can be traced with give the oracle's samples bit for bit: node table held
+    eight-fold in LDS (one copy per combination of direction signs, the default for a few dozen nodes), held once
+    (PT_NO_OCTANT_ROWS), left in memory in storage order and nearer child first; each with the shadow rays that can
+    only add zeros dropped (default) and traced (PT_TRACE_NULL_SHADOW_RAYS); on the tree of the file and on the
+    device-built one (whose root is not the file's: the walk from LDS starts below it)."""
+    loaded = pt.LoadedScene(os.path.join(golden_dir, "cornell_glossy.ptscene"))
+    scene = pt.FlatScene.from_desc(loaded.desc())  # (a copy whose tree can be exchanged)
+    cam = pt.load_camera(os.path.join(golden_dir, "cornell_wide.ptcam"))
+    p = pt.make_params(96, 54, 3)
+    d = scene.desc()
+    want = oracle.render_samples(C.byref(d), cam, p, math_mode=1)
+    dev = pt.DeviceScene(scene)
+    try:
+        for built in (False, True):
+            if built:
+                dev.build_bvh_device(0.0, 0.0)
+                scene.nodes = dev.get_bvh()
+                d = scene.desc()
+                want = oracle.render_samples(C.byref(d), cam, p, math_mode=1)
+            for walk in ({}, {"PT_NO_OCTANT_ROWS": "1"}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}, {"PT_NO_LDS_SCENE": "1"}):
+                for rays in ({}, {"PT_TRACE_NULL_SHADOW_RAYS": "1"}):
+                    env = dict(walk, **rays)
+                    os.environ.update(env)
+                    try:
+                        got = dev.render_samples(cam, p)
+                    finally:
+                        for k in env:
+                            del os.environ[k]
+                    assert same_bits(got, want), (built, env)
+    finally:
+        dev.close()
+
+
 def test_render_multi_with_two_handles_on_one_gpu(cornell, oracle):
     """pt_render_multi rehearsed on one GPU: two scene handles (as if on two GPUs), one host thread each.  Tiles:
     the single-handle image bit for bit (also with a rectangle and a sample range, leaving the other pixels
