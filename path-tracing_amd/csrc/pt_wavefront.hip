@@ -136,6 +136,10 @@ constexpr uint32_t kCtrWords = (kCtrWork + 2 * kShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
+// (the count of path numbers handed out by a shard keeps growing while a batch drains, a region's worth per iteration:
+// it must stop at the top rather than start again)
+PT_DEV uint32_t addSaturating(uint32_t a, uint32_t b) { return a > 0xFFFFFFFFu - b ? 0xFFFFFFFFu : a + b; }
+
 // Two independent reservations for the threads of a block of WAVES waves: one unit for every
 // thread that wants one, by wave ballots, a prefix sum over the wave counts in LDS, and ONE
 // atomic per block and reservation (two barriers).
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
             counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
             // the generateKernel before this launch gave path numbers to the places of region q that the
             // continuing paths had left free
-            counters[q * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride];
+            counters[q * kCtrStride] = addSaturating(counters[q * kCtrStride], pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride]);
             counters[(kCtrLive + q) * kCtrStride] = 0;
         }
     // small scenes: node and surface tables are copied into LDS once per block, which takes the
@@ -693,7 +697,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
             counters[(kCtrHit + q) * kCtrStride] = 0; // the list of the previous iteration has been worked off
             // the generateKernel before this launch gave path numbers to the places of region q that the
             // continuing paths had left free
-            counters[q * kCtrStride] += pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride];
+            counters[q * kCtrStride] = addSaturating(counters[q * kCtrStride], pool.nSlots / kShards - counters[(kCtrLive + q) * kCtrStride]);
             counters[(kCtrLive + q) * kCtrStride] = 0;
         }
     __shared__ uint32_t sFill[2 * kShards];
@@ -1908,7 +1912,8 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
     perBatch = std::min<uint64_t>(perBatch, nsTotal);
     if (keepSamples && perBatch < nsTotal)
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
-    uint64_t nSlots = std::min<uint64_t>(w.fixed ? w.fixedSlots : envU64("PT_WAVEFRONT_SLOTS", 1u << 24), idsPerSample * perBatch);
+    // (32 M records per pool: 4 % more than 16 M on the Cornell box, 5 % on the scenes in memory, 64 M no more)
+    uint64_t nSlots = std::min<uint64_t>(w.fixed ? w.fixedSlots : envU64("PT_WAVEFRONT_SLOTS", 1u << 25), idsPerSample * perBatch);
     const uint64_t slotUnit = uint64_t(kClassifyRecords) * kShards; // every shard's region and list is whole blocks
     nSlots = std::max<uint64_t>((nSlots + slotUnit - 1) / slotUnit * slotUnit, slotUnit);
     if (w.fixed) {
