@@ -12,11 +12,14 @@ sum-reduce inside the timed region.  Rank 0 prints one JSON line.
 
 The line also carries
   roofline      for the kernel with the most device time: what it achieves against the limit that binds it.
-                Scenes whose tables fit LDS: FP32 vector flops of the walk (30 per box test, 60 per surface test,
-                counted by the instrumented kernel) over the kernel's duration against the FP32 vector peak.
-                Scenes in memory: bytes the executed walk has to move (32 per box row, 48 per surface test, the
-                ray records in and out; counted by the instrumented kernel) over the duration against the HBM peak,
-                beside the HBM bytes rocprofv3's counters saw for the same launch (profiles/).
+                A tracing kernel of a scene whose tables fit LDS: FP32 vector flops of the walk (30 per box test, 60
+                per surface test, counted by the instrumented kernel) over the kernel's duration against the FP32
+                vector peak.  A tracing kernel of a scene in memory: bytes the executed walk has to move (32 per box
+                row, 48 per surface test, the ray records in and out; counted by the instrumented kernel) over the
+                duration against the HBM peak.  The shading kernel (which has overtaken the tracing kernel on the
+                small scenes): the bytes of path state it gathers and scatters per shaded vertex against the HBM
+                peak.  Each beside the HBM bytes rocprofv3's counters saw for the same launch (profiles/).
+  roofline_trace  the same for the tracing kernel when another kernel has the most time.
   rmse          the rendered image, averaged over 20x20 pixel blocks, against a converged 96x54 image of the same
                 view rendered by the reference with its own generator (tests/golden/converged_*.npz).
   cpu_baseline  the compiled reference (oracle/_ref/libpt_ref_fast.so: the reference's own pathSample / BVH /
@@ -339,9 +342,10 @@ def main():
                          + 57 * walk_per_sample["retry_rays"],
                 "flops": 30 * walk_per_sample["retry_node_visits"] + 60 * walk_per_sample["retry_surface_tests"]},
             "shadeHitsKernel": {
-                # per shaded vertex: the path record in (88 bytes) and out (72), the surface's rows and attributes (64+)
-                # and a shadow-queue entry (48); per light-pdf test a 48-byte surface row; 12 bytes per finished sample
-                "bytes": ref_per_sample["vertices"] * (88 + 72 + 64 + 48) + 48 * ref_per_sample["light_tests"] + 12,
+                # per shaded vertex: its place in the hit list (4 bytes), the path record in (88) and out (72), the surface's
+                # attributes and plane normal or vertices (32 to 64: 48 taken), a shadow-queue entry (48); 12 bytes per
+                # finished sample.  (The rows of the lights are the same for every lane: scalar loads that stay in cache.)
+                "bytes": ref_per_sample["vertices"] * (4 + 88 + 72 + 48 + 48) + 12,
                 "flops": 300 * ref_per_sample["vertices"] + 60 * ref_per_sample["light_tests"]},
         }
         in_lds = kernel_times.get("traceKernel", (0, 0))[0] > 0 and kernel_times.get("traceOrderedKernel", (0, 0))[0] == 0 \
@@ -377,7 +381,19 @@ def main():
                   "samples_per_launch": dk.get("samples_per_launch"), "traffic": traffic, "traffic_note": traffic_note,
                   "algorithmic_bytes_per_launch": alg_bytes_launch,
                   "traffic_over_algorithmic": (traffic / alg_bytes_launch) if traffic and alg_bytes_launch else None}
-        if in_lds:
+        if dominant == "shadeHitsKernel":
+            # the shading kernel gathers path records through the hit list and scatters the paths that go on: what it
+            # is priced against is the memory system
+            ach = dk.get("algorithmic_GBps", 0.0)
+            roofline = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                            traffic_GBps=dk.get("hbm_GBps"),
+                            traffic_frac=(dk["hbm_GBps"] / HBM_PEAK_GBS) if dk.get("hbm_GBps") else None,
+                            bytes_per_sample=per_sample[dominant]["bytes"],
+                            note="the shading kernel has the most device time by a small margin over the tracing kernel "
+                                 "(`roofline_trace`); achieved = bytes it has to move per shaded vertex (hit-list entry, path "
+                                 "record in and out, surface attributes, shadow-queue entry) / duration; it waits for those "
+                                 "gathers 64 % of its wave-cycles (profiles/r02_pmc_sq_cornell.txt)")
+        elif in_lds:
             # node and surface tables are in LDS: the walk never touches HBM, what binds is vector issue
             ach = dk.get("algorithmic_TFLOPs", 0.0)
             roofline = dict(common, bound="fp32-valu", achieved=ach, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
@@ -398,6 +414,24 @@ def main():
                             note="achieved = bytes the executed walk has to move (32 per box row, 48 per surface test, ray "
                                  "records in and out; counts from the instrumented kernel) / kernel duration; `traffic` = "
                                  "HBM bytes per launch from rocprofv3 counters (profiles/)")
+        # the tracing kernel against its own limit, whichever kernel has the most time
+        trace_name = max((n for n in kernels if n in ("traceKernel", "traceOrderedKernel")), key=lambda n: kernels[n]["ms_per_step"],
+                         default=None)
+        roofline_trace = None
+        if trace_name and trace_name != dominant:
+            tk = kernels[trace_name]
+            if in_lds:
+                ach = tk.get("algorithmic_TFLOPs", 0.0)
+                roofline_trace = {"kernel": trace_name, "kernel_avg_us": tk["avg_us"], "bound": "fp32-valu", "achieved": ach,
+                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS,
+                                  "peak_unfused": VALU_PEAK_UNFUSED_TFLOPS, "frac_unfused": ach / VALU_PEAK_UNFUSED_TFLOPS,
+                                  "flops_per_sample": per_sample[trace_name]["flops"],
+                                  "traffic": tk.get("hbm_bytes_per_launch")}
+            else:
+                ach = tk.get("algorithmic_GBps", 0.0)
+                roofline_trace = {"kernel": trace_name, "kernel_avg_us": tk["avg_us"], "bound": "hbm", "achieved": ach,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                  "traffic": tk.get("hbm_bytes_per_launch")}
         # all kernels of one step together against both limits
         total_flops = sum(per_sample[n]["flops"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
                           for n in kernels if n in per_sample)
@@ -428,6 +462,7 @@ def main():
             "rmse": rmse_against_converged(image, extra.get("converged"), spp)
                     if not args.sqrt_spp and not (frames and world > 1) else None,
             "roofline": roofline,
+            "roofline_trace": roofline_trace,
             "whole_step": whole,
             "kernels": kernels,
             "work_per_sample": ref_per_sample,
