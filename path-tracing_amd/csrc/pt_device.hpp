@@ -1321,15 +1321,16 @@ __device__ inline void lightsPdf2(const DevScene& sc, V3 origin, V3 dirA, V3 dir
 }
 
 // pathSample, reference src/15/pathtracer.cpp:50-130
+// The loop may be entered in the middle of a path: at segment `firstSegment` with the radiance and throughput
+// gathered so far and, if `known`, with the closest hit of `ray` already found (`firstHit`).
 template <bool COUNT>
-__device__ inline V3 pathSample(const DevScene& sc, const PathParams& pp, Ray ray, Rng<COUNT>& rng, Counters* cnt)
+__device__ inline V3 pathSampleFrom(const DevScene& sc, const PathParams& pp, Ray ray, Rng<COUNT>& rng, Counters* cnt,
+                                    int firstSegment, V3 radiance, V3 throughput, bool known, HitLite firstHit)
 {
     const float MinHit = 0.0001f;
     const float MaxHit = kFltMax;
-    V3 radiance = v3(0.0f);
-    V3 throughput = v3(1.0f);
-    for (int segment = 0; segment < pp.maxSegments; segment++) {
-        HitLite hl = closestHit<COUNT>(sc, ray, MinHit, MaxHit, cnt);
+    for (int segment = firstSegment; segment < pp.maxSegments; segment++) {
+        HitLite hl = (known && segment == firstSegment) ? firstHit : closestHit<COUNT>(sc, ray, MinHit, MaxHit, cnt);
         if (hl.sid == PT_NO_HIT) {
             if (sc.envmap.type != PT_ENV_NONE)
                 radiance = radiance + throughput * envmapValue(sc, ray.direction);
@@ -1394,6 +1395,12 @@ __device__ inline V3 pathSample(const DevScene& sc, const PathParams& pp, Ray ra
         }
     }
     return radiance;
+}
+
+template <bool COUNT>
+__device__ inline V3 pathSample(const DevScene& sc, const PathParams& pp, Ray ray, Rng<COUNT>& rng, Counters* cnt)
+{
+    return pathSampleFrom<COUNT>(sc, pp, ray, rng, cnt, 0, v3(0.0f), v3(1.0f), false, noHit());
 }
 
 // Camera::getRay, reference src/15/camera.hpp:34-55

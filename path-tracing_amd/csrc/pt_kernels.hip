@@ -812,7 +812,7 @@ int pt_scene_kernel_times(pt_scene* scene, pt_kernel_time* out, int capacity, in
     scene->kt.collect();
     static const char* const names[KernelTimes::kKinds] = { "generateKernel", "traceKernel", "shadeHitsKernel",
                                                             "resolveKernel", "classifyKernel", "traceOrderedKernel",
-                                                            "traceRetryKernel" };
+                                                            "traceRetryKernel", "finishPathsKernel" };
     *count = KernelTimes::kKinds;
     for (int k = 0; k < KernelTimes::kKinds && k < capacity; k++) {
         std::memset(&out[k], 0, sizeof(out[k]));

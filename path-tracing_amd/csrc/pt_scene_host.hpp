@@ -78,7 +78,7 @@ struct WavefrontBuffers {
 // stream a kernel is launched on.  begin(k) / end() bracket one launch; collect() (once the
 // streams have been synchronised) adds the elapsed times to the sums.
 struct KernelTimes {
-    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kTraceOrdered, kTraceRetry, kKinds };
+    enum Kind { kGenerate = 0, kTrace, kShade, kResolve, kClassify, kTraceOrdered, kTraceRetry, kFinish, kKinds };
     struct Span {
         size_t start, stop; // indices into `events`
         int kind;

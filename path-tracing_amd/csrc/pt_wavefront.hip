@@ -1428,6 +1428,49 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
     }
 }
 
+// The last paths of a batch, one lane each, to their end.  Once every path of a batch has been started the pool only
+// drains, for as many iterations as the longest path has segments left, and an iteration costs four launches and a
+// wave's walk however few paths it holds.  When few are left (see runBatch) the pool is traced once more -- which also
+// delivers the shadow rays queued last -- and this kernel takes every record in use with its hit and runs the rest of
+// pathSample for it (reference src/15/pathtracer.cpp:50-130; pathSampleFrom: the very functions of the other kernels,
+// the storage-order walk and the shadow rays in line), then writes the sample.
+__global__ void __launch_bounds__(64) finishPathsKernel(DevScene sc, Pool pool, PathParams pp, const uint32_t* __restrict__ counters,
+                                                      float* __restrict__ samples, uint32_t blocksPerRegion)
+{
+    const uint32_t region = blockIdx.x / blocksPerRegion;
+    const uint32_t inRegion = (blockIdx.x - region * blocksPerRegion) * 64u + threadIdx.x;
+    if (inRegion >= counters[(kCtrOcc + region) * kCtrStride])
+        return;
+    const uint32_t slot = region * (pool.nSlots / kShards) + inRegion;
+    const float4 d_s = pool.d_s[slot];
+    if (((fbits(d_s.w) >> 16) & 3u) != kActive)
+        return;
+    const float4 o_t = pool.o_t[slot];
+    const float4 thr_n = pool.thr_n[slot];
+    const float4 rad_p = pool.rad_p[slot];
+    const uint4 hw = pool.hit[slot];
+    const uint2 kw = pool.key[slot];
+    Rng<false> rng;
+    rng.key = uint64_t(kw.x) | (uint64_t(kw.y) << 32);
+    rng.n = fbits(thr_n.w);
+    rng.cnt = nullptr;
+    HitLite hl = noHit();
+    if (hw.x != PT_NO_HIT) {
+        hl.sid = hw.x & 0x7FFFFFFFu;
+        hl.backside = (hw.x >> 31) != 0;
+        hl.a = __uint_as_float(hw.y);
+        hl.u = __uint_as_float(hw.z);
+        hl.v = __uint_as_float(hw.w);
+    }
+    const Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
+    const V3 radiance = pathSampleFrom<false>(sc, pp, ray, rng, nullptr, int(fbits(d_s.w) & 0xFFFFu), v3(rad_p.x, rad_p.y, rad_p.z),
+                                              v3(thr_n.x, thr_n.y, thr_n.z), true, hl);
+    float* p = samples + 3 * size_t(fbits(rad_p.w));
+    p[0] = radiance.x;
+    p[1] = radiance.y;
+    p[2] = radiance.z;
+}
+
 // `next` = the pool being filled: the places of every region behind the paths that go on
 #ifndef PT_GENERATE_ROOT_TEST
 #define PT_GENERATE_ROOT_TEST 1
@@ -1825,6 +1868,9 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrLive + q) * kCtrStride),
                                   int(nSlots / kShards), 1, stream));
     bool exhaustedBefore = false; // every path number had been handed out at the previous check already
+    // paths left below which the batch is finished by finishPathsKernel (0: never)
+    // (4 K to 1 M measured alike: what decides is when the host next looks at the counters)
+    const uint64_t finishLimit = envU64("PT_FINISH_PATHS", 32768);
     uint64_t iter = 0;
     // Blocks per region (per list) of the classifying, shading and generating launches: all of it while paths are
     // being started.  Once the last one has been, the pool only drains -- with Russian roulette for a hundred
@@ -1875,6 +1921,30 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
         if (exhaustedBefore && alive == 0)
             break;
         exhaustedBefore = exhausted;
+        if (exhausted && finishLimit > 0 && !sc->walkStatsOn) {
+            // few paths left: one more tracing launch (their hits, and the shadow rays queued last), then every path
+            // to its end in one kernel instead of an iteration per segment of the longest
+            uint32_t mostInUse = 0;
+            uint64_t inUseAll = 0;
+            for (uint32_t q = 0; q < kShards; q++) {
+                const uint32_t inUse = w.hostCounters[(kCtrOcc + q) * kCtrStride];
+                mostInUse = std::max(mostInUse, inUse);
+                inUseAll += inUse;
+            }
+            if (inUseAll <= finishLimit) {
+                const Pool& cur = pools[iter & 1];
+                launchTraceFor(sc, w, cur, stream, int(iter & 1), dyn, lds);
+                if (mostInUse > 0) {
+                    const uint32_t perRegion = (mostInUse + 63u) / 64u;
+                    sc->kt.begin(KernelTimes::kFinish, stream);
+                    hipLaunchKernelGGL(finishPathsKernel, dim3(perRegion * kShards), dim3(64), 0, stream, sc->dev, cur, a.pp, w.counters,
+                                       w.samples, perRegion);
+                    sc->kt.end(stream);
+                }
+                HIP_TRY(hipGetLastError());
+                return PT_OK;
+            }
+        }
         if (exhausted) {
             // No launch starts a path any more.  A list of hits is made from the records of every region, and the paths
             // of a list go on in one region, so what bounds a region and a list from here on is the number of all paths

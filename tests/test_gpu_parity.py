@@ -292,8 +292,10 @@ def test_tracing_kernel_variants_of_a_small_scene(golden_dir, oracle):
     """The walks a small static scene can be traced with give the oracle's samples bit for bit: node table held
     eight-fold in LDS (one copy per combination of direction signs, the default for a few dozen nodes), held once
     (PT_NO_OCTANT_ROWS), left in memory in storage order and nearer child first; each with the shadow rays that can
-    only add zeros dropped (default) and traced (PT_TRACE_NULL_SHADOW_RAYS); on the tree of the file and on the
-    device-built one (whose root is not the file's: the walk from LDS starts below it)."""
+    only add zeros dropped (default) and traced (PT_TRACE_NULL_SHADOW_RAYS), and with the last paths of the batch
+    left to the iterations (PT_FINISH_PATHS=0) or all paths finished by the one-lane-per-path kernel as soon as the
+    last one has been started; on the tree of the file and on the device-built one (whose root is not the file's:
+    the walk from LDS starts below it)."""
     loaded = pt.LoadedScene(os.path.join(golden_dir, "cornell_glossy.ptscene"))
     scene = pt.FlatScene.from_desc(loaded.desc())  # (a copy whose tree can be exchanged)
     cam = pt.load_camera(os.path.join(golden_dir, "cornell_wide.ptcam"))
@@ -309,7 +311,7 @@ def test_tracing_kernel_variants_of_a_small_scene(golden_dir, oracle):
                 d = scene.desc()
                 want = oracle.render_samples(C.byref(d), cam, p, math_mode=1)
             for walk in ({}, {"PT_NO_OCTANT_ROWS": "1"}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}, {"PT_NO_LDS_SCENE": "1"}):
-                for rays in ({}, {"PT_TRACE_NULL_SHADOW_RAYS": "1"}):
+                for rays in ({}, {"PT_TRACE_NULL_SHADOW_RAYS": "1"}, {"PT_FINISH_PATHS": "0"}, {"PT_FINISH_PATHS": "100000000"}):
                     env = dict(walk, **rays)
                     os.environ.update(env)
                     try:
