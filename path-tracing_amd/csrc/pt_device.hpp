@@ -534,9 +534,10 @@ PT_DEV void sphereCR(const DevScene& sc, uint32_t sid, float time, V3& c, float&
     c = v3(r0.x, r0.y, r0.z);
     r = r1.x;
     T = xformIdentity();
-    const pt_sphere& q = sc.spheres[sphereId];
-    if (q.animation >= 0) {
-        T = animationAt<PM>(sc.animations[q.animation], time);
+    // (the sphere's animation number travels in its row: no look into the sphere table)
+    const int animation = int(fbits(r1.z));
+    if (animation >= 0) {
+        T = animationAt<PM>(sc.animations[animation], time);
         if (fbits(r0.w) == kSphDynamic) {
             c = apply(T, c);
             r *= T.scaling.x;
