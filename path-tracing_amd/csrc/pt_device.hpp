@@ -78,10 +78,10 @@ struct DevScene {
     const DevMesh* meshes;
     const pt_sphere* spheres;
     const uint32_t* lights;
-    // Per surface, for a triangle with a fixed pose and no vertex normals (flag 64 in surfAttr): the unit normal of
-    // its plane, normalize(cross(B - A, C - A)) as the hit record and the light pdf compute it, and half the length of
-    // that cross product (its area) -- worked out once at upload with the same operations.  lightGeo repeats the row
-    // of light i (w < 0: not such a triangle).
+    // Per surface, for a triangle with a fixed pose, no vertex normals and, if its mesh is posed, no tangents (flag
+    // 64 in surfAttr): the unit normal of its plane, normalize(cross(B - A, C - A)) as the hit record and the light
+    // pdf compute it, and half the length of that cross product (its area) -- worked out once at upload with the same
+    // operations.  lightGeo repeats the row of light i (w < 0: not such a triangle).
     const float4* faceN;
     const float4* lightGeo;
     const pt_material* materials;
@@ -776,8 +776,8 @@ __device__ inline Hit makeHit(const DevScene& sc, const Ray& ray, const HitLite&
     hr.position = rayAt(ray, h.a);
     const uint4 attr = sc.surfAttr[h.sid];
     if ((attr.w >> 24) & 64u) {
-        // a triangle with a fixed pose and no vertex normals, of a mesh without animation: the normal of its plane
-        // was worked out at upload, the vertices are not needed
+        // a triangle with a fixed pose and no vertex normals (and no tangents for a pose to turn): the normal of
+        // its plane was worked out at upload, the vertices are not needed
         const uint32_t flags = attr.w >> 24;
         const float4 fn = sc.faceN[h.sid];
         V3 nrm = v3(fn.x, fn.y, fn.z);

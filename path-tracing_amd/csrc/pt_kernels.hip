@@ -505,7 +505,9 @@ try {
             surf[3 * i + 2] = make_float4(C.x, C.y, C.z, bitsf(s.index));
             uint32_t flags = (m.has_normals ? 1u : 0u) | (m.has_texcoords ? 2u : 0u) | (m.has_tangents ? 4u : 0u)
                 | (m.animation >= 0 ? 8u : 0u) | materialNeeds(m.material, 0);
-            if (kind == kTriStatic && !m.has_normals && m.animation < 0) {
+            // (a mesh with a constant pose has been posed above; what its pose would still turn when shading are
+            // vertex normals and tangents, so it qualifies if it has neither)
+            if (kind == kTriStatic && !m.has_normals && (m.animation < 0 || !m.has_tangents)) {
                 // the normal of the triangle's plane and its area, with the operations of the hit record
                 // (reference src/15/surface_triangle.hpp:151-156) and of Surface::p (:201-204)
                 const V3 edgeCross = cross(B - A, C - A);
