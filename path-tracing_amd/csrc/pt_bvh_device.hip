@@ -1118,6 +1118,11 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         HIP_TRY(hipStreamSynchronize(stream));
         scene->dev.n_nodes = 1;
         scene->dev.wide = scene->wide; // no inner node: no row is ever read
+        const int rcLinks = ptWavefrontBuildWalkLinks(scene, t0, stream);
+        if (rcLinks != PT_OK) {
+            scene->dev.n_nodes = 0;
+            return rcLinks;
+        }
         HIP_TRY(call.done(stream));
         return PT_OK;
     }
@@ -1241,9 +1246,14 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
                                uint32_t(2 * n - 1), base, step, scene->wide);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(call.done(stream));
     scene->dev.wide = gridOk ? scene->wide : nullptr; // without rows: storage-order walk only
     scene->dev.n_nodes = uint32_t(2 * n - 1);
+    const int rcLinks = ptWavefrontBuildWalkLinks(scene, t0, stream);
+    if (rcLinks != PT_OK) {
+        scene->dev.n_nodes = 0;
+        return rcLinks;
+    }
+    HIP_TRY(call.done(stream));
     return PT_OK;
 }
 

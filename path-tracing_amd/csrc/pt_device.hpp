@@ -84,6 +84,12 @@ struct DevScene {
     // operations.  lightGeo repeats the row of light i (w < 0: not such a triangle).
     const float4* faceN;
     const float4* lightGeo;
+    // Scenes whose tables are traced from LDS: per node the two link words of that walk (see packNodeLinks), made
+    // once per tree, and in entry n_nodes the node the walk starts at.  The table may leave inner nodes out of the
+    // walk: an inner node's box only decides whether its subtree is looked at, and a ray that misses it misses every
+    // box inside it, so the walk tests the same surfaces in the same order without it.  Null: links as packNodeLinks
+    // makes them, start below the root.
+    const uint2* walkLinks;
     const pt_material* materials;
     const pt_texture* textures;
     const float* texels;
@@ -701,9 +707,9 @@ PT_DEV uint32_t octantOf(const Ray& ray)
     return (ray.invDirection.x < 0.0f ? 1u : 0u) | (ray.invDirection.y < 0.0f ? 2u : 0u) | (ray.invDirection.z < 0.0f ? 4u : 0u);
 }
 
-PT_DEV void octantRow(uint32_t node, uint32_t octant, float4 n0, float4 n1, float4& r0, float4& r1)
+// (n1 comes with its link words packed)
+PT_DEV void octantRow(uint32_t octant, float4 n0, float4 n1, float4& r0, float4& r1)
 {
-    packNodeLinks(node, n1);
     const bool nx = octant & 1u, ny = octant & 2u, nz = octant & 4u;
     r0 = make_float4(nx ? n0.w : n0.x, nx ? n0.x : n0.w, ny ? n1.x : n0.y, ny ? n0.y : n1.x);
     r1 = make_float4(nz ? n1.y : n0.z, nz ? n0.z : n1.y, n1.z, n1.w);

@@ -646,6 +646,7 @@ try {
         pt_scene_destroy(sc);
         return fail(PT_ERR_DEVICE, "cannot create timing events");
     }
+    if ((rc = ptWavefrontBuildWalkLinks(sc, 0.0f, nullptr)) != PT_OK) return bail(rc);
     *out_scene = sc;
     return PT_OK;
 } catch (...) {
@@ -680,6 +681,12 @@ try {
     } else {
         scene->dev.wide = nullptr;
     }
+    rc = ptWavefrontBuildWalkLinks(scene, 0.0f, nullptr);
+    if (rc != PT_OK) {
+        scene->dev.n_nodes = 0;
+        return rc;
+    }
+    HIP_TRY(call.done(nullptr));
     return PT_OK;
 } catch (...) {
     return ptint::caught();

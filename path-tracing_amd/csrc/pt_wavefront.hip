@@ -415,13 +415,23 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     if (LDS) {
         static_assert(!OCT || (LDS && !DYN), "copies per direction sign: static scenes in LDS only");
         const uint32_t nNode4 = (OCT ? kOctantRow4 : 2u) * sc.n_nodes, nSurf4 = 3u * sc.n_surfaces;
+        // the two link words of every node as this walk wants them: from the scene's table, which may leave inner
+        // nodes out of the walk (DevScene::walkLinks), else made here
         if (OCT) {
             for (uint32_t node = threadIdx.x; node < sc.n_nodes; node += BLOCK) {
-                const float4 n0 = sc.nodes[2u * node], n1 = sc.nodes[2u * node + 1u];
+                const float4 n0 = sc.nodes[2u * node];
+                float4 n1 = sc.nodes[2u * node + 1u];
+                if (sc.walkLinks) {
+                    const uint2 l = sc.walkLinks[node];
+                    n1.z = __uint_as_float(l.x);
+                    n1.w = __uint_as_float(l.y);
+                } else {
+                    packNodeLinks(node, n1);
+                }
 #pragma unroll
                 for (uint32_t octant = 0; octant < 8u; octant++) {
                     float4 r0, r1;
-                    octantRow(node, octant, n0, n1, r0, r1);
+                    octantRow(octant, n0, n1, r0, r1);
                     ldsGeo[2u * (octant * sc.n_nodes + node)] = r0;
                     ldsGeo[2u * (octant * sc.n_nodes + node) + 1u] = r1;
                 }
@@ -429,8 +439,15 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
         } else {
             for (uint32_t i = threadIdx.x; i < nNode4; i += BLOCK) {
                 float4 v = sc.nodes[i];
-                if (i & 1u)
-                    packNodeLinks(i >> 1, v);
+                if (i & 1u) {
+                    if (sc.walkLinks) {
+                        const uint2 l = sc.walkLinks[i >> 1];
+                        v.z = __uint_as_float(l.x);
+                        v.w = __uint_as_float(l.y);
+                    } else {
+                        packNodeLinks(i >> 1, v);
+                    }
+                }
                 ldsGeo[i] = v;
             }
         }
@@ -452,6 +469,16 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     }
     const uint32_t lane = laneId();
     const uint64_t below = (1ull << lane) - 1ull;
+    // Tables in LDS: where the walk begins.  Without a link table, at the root's first child: the root's box is the
+    // merge of its children's, and the slab arithmetic is monotone in the planes, so a ray that misses it misses
+    // both children too -- the same surfaces get tested, one box test fewer for every ray that hits it (which is
+    // every ray that starts inside the scene).  A link table names its own first node, by the same argument.
+    uint32_t walkStart = 0;
+    if (LDS) {
+        walkStart = sc.n_nodes > 1u ? 1u : 0u;
+        if (sc.walkLinks)
+            walkStart = uint32_t(__builtin_amdgcn_readfirstlane(int(sc.walkLinks[sc.n_nodes].x)));
+    }
     // 0: rays of paths (items are pool records), 1: shadow rays (items are queue entries); half of the waves begin
     // with either kind and go over to the other when theirs is worked off and their lanes are empty (see takeRun)
     // taken runs: half of the waves begin with either kind and go over to the other when theirs is worked off and
@@ -529,11 +556,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                     if (OCT)
                         rows = nodes + 2u * sc.n_nodes * octantOf(ray);
                     amax = kFltMax;
-                    // Tables in LDS: the walk begins at the root's first child.  The root's box is the merge of its
-                    // children's, and the slab arithmetic is monotone in the planes, so a ray that misses it misses
-                    // both children too: the same surfaces get tested, one box test fewer for every ray that hits it
-                    // (which is every ray that starts inside the scene).
-                    cur = LDS && sc.n_nodes > 1u ? 1u : 0u;
+                    cur = walkStart;
                     pending = kInner;
                     best = noHit();
                     if (STATS) {
@@ -1766,6 +1789,206 @@ bool sceneFitsLds(const pt_scene* sc)
         && ldsTableBytes(sc) <= 2 * kLdsGeoLimit && std::getenv("PT_NO_LDS_SCENE") == nullptr;
 }
 
+// ---- the link table of the walk from LDS (DevScene::walkLinks) ----
+//
+// The storage-order walk tests every box on its way; an inner node's box only decides whether the boxes inside it
+// are looked at.  A ray that misses a box misses every box inside it (the slab arithmetic is monotone in the planes,
+// see aabbEntry), and a leaf's own box is always tested before its surface, so taking an inner node OUT of the walk
+// -- going straight on to its first child -- changes neither which surfaces are tested nor their order: only the
+// number of box tests.  Leaving node P out saves one test whenever P's box is hit and costs the tests of its
+// children's boxes whenever it is missed, so it pays for boxes that most rays hit: the upper levels of a tree seen
+// from inside the scene, and every node whose first child has the very same box (the two triangles of an
+// axis-parallel wall): a miss of that child is a miss of P, and the child's link for a miss is P's.
+//
+// How often a box is hit is measured, not guessed: one block traces a few thousand rays between random points of
+// the scene's surfaces (chosen by area, directions weighted by the cosine at the start, as bounced rays are) through
+// the full tree and counts visits and hits per node; one thread then decides bottom-up -- leave P out if
+// (visits - hits) x (boxes tested instead after a miss) < visits -- and writes for every node the two link words of
+// the walk (packNodeLinks' layout) and, behind them, the node the walk starts at.  Two tables are made: all nodes
+// (start below the root, as a walk without table has it) and the pruned one.
+constexpr uint32_t kWalkLinkNodes = 1024; // a tree that fits LDS has a few hundred nodes at most
+constexpr uint32_t kWalkLinkRays = 8;     // per thread of the one block
+__global__ void __launch_bounds__(1024) walkLinksKernel(DevScene sc, float time, uint2* __restrict__ pruned)
+{
+    __shared__ uint32_t visits[kWalkLinkNodes], hits[kWalkLinkNodes];
+    __shared__ uint32_t esc[kWalkLinkNodes], leafWord[kWalkLinkNodes], escTo[kWalkLinkNodes];
+    __shared__ uint16_t frontier[kWalkLinkNodes];
+    __shared__ uint8_t sameBox[kWalkLinkNodes], out_[kWalkLinkNodes], chain[kWalkLinkNodes];
+    __shared__ float cum[kWalkLinkNodes / 2 + 1];
+    const uint32_t n = sc.n_nodes, nSurf = sc.n_surfaces;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        visits[i] = hits[i] = 0;
+        const float4 a0 = sc.nodes[2u * i], a1 = sc.nodes[2u * i + 1u];
+        esc[i] = fbits(a1.z);
+        leafWord[i] = fbits(a1.w);
+        // (bit patterns: a box is "the same" only if a test of it is the same computation)
+        bool same = false;
+        if ((fbits(a1.w) & kInnerBit) && i + 1u < n) {
+            const float4 b0 = sc.nodes[2u * i + 2u], b1 = sc.nodes[2u * i + 3u];
+            same = fbits(a0.x) == fbits(b0.x) && fbits(a0.y) == fbits(b0.y) && fbits(a0.z) == fbits(b0.z) && fbits(a0.w) == fbits(b0.w)
+                && fbits(a1.x) == fbits(b1.x) && fbits(a1.y) == fbits(b1.y);
+        }
+        sameBox[i] = same ? 1 : 0;
+    }
+    // surfaces by area
+    for (uint32_t s = threadIdx.x; s < nSurf; s += blockDim.x) {
+        const float4 r0 = sc.surf[3u * s];
+        float area;
+        if (fbits(r0.w) <= kTriDynamic) {
+            V3 A, B, C;
+            triVertices(sc, s, time, A, B, C);
+            const V3 cr = cross(B - A, C - A);
+            area = 0.5f * ::sqrtf(dot(cr, cr));
+        } else {
+            V3 c;
+            float r;
+            Xform T;
+            uint32_t sphereId;
+            sphereCR(sc, s, time, c, r, T, sphereId);
+            area = 4.0f * kPi * r * r;
+        }
+        cum[s + 1u] = (area == area && area > 0.0f && area < 1.0e30f) ? area : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cum[0] = 0.0f;
+        for (uint32_t s = 0; s < nSurf; s++)
+            cum[s + 1u] += cum[s];
+    }
+    __syncthreads();
+    const float total = cum[nSurf];
+    auto pick = [&](float u) {
+        const float x = u * total;
+        uint32_t lo = 0, hi = nSurf; // first s with cum[s + 1] > x
+        while (lo + 1u < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cum[mid] <= x)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    auto pointOn = [&](uint32_t s, float u0, float u1, V3& normal) {
+        const float4 r0 = sc.surf[3u * s];
+        if (fbits(r0.w) <= kTriDynamic) {
+            V3 A, B, C;
+            triVertices(sc, s, time, A, B, C);
+            const V3 b = uniformInTriangle(u0, u1);
+            normal = cross(B - A, C - A);
+            return b.x * A + b.y * B + b.z * C;
+        }
+        V3 c;
+        float r;
+        Xform T;
+        uint32_t sphereId;
+        sphereCR(sc, s, time, c, r, T, sphereId);
+        normal = uniformOnSphere(u0, u1);
+        return c + r * normal;
+    };
+    if (total > 0.0f && nSurf > 1u) {
+        for (uint32_t k = 0; k < kWalkLinkRays; k++) {
+            const uint64_t key = pt_rng_key(0x6c696e6b73ull, threadIdx.x, k);
+            const uint32_t sa = pick(pt_rng_in01(key, 0)), sb = pick(pt_rng_in01(key, 1));
+            V3 na, nb;
+            const V3 pa = pointOn(sa, pt_rng_in01(key, 2), pt_rng_in01(key, 3), na);
+            const V3 pb = pointOn(sb, pt_rng_in01(key, 4), pt_rng_in01(key, 5), nb);
+            const V3 d = pb - pa;
+            const float len = ::sqrtf(dot(d, d)), nlen = ::sqrtf(dot(na, na));
+            if (!(len > 0.0f) || !(nlen > 0.0f) || !(len < 1.0e30f))
+                continue;
+            const V3 dir = d / len;
+            // a bounced ray leaves its surface with a density proportional to the cosine
+            if (!(fabs_(dot(na, dir)) / nlen > pt_rng_in01(key, 6)))
+                continue;
+            const Ray ray = makeRay(pa, dir, time);
+            float amax = kFltMax;
+            HitLite best = noHit();
+            uint32_t cur = 0;
+            while (cur < n) {
+                uint32_t pending;
+                const uint32_t at = cur;
+                nodeStep<false>(sc.nodes, ray, 0.0001f, amax, cur, pending);
+                atomicAdd(&visits[at], 1u);
+                if (pending != kInner || ((leafWord[at] & kInnerBit) && cur == at + 1u))
+                    atomicAdd(&hits[at], 1u);
+                if (pending != kInner && surfaceTest<true>(sc, sc.surf, pending, ray, 0.0001f, amax, best))
+                    amax = best.a;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    // Bottom-up (children lie behind their parent): out_[i] = node i is left out; frontier[i] = boxes tested when the
+    // walk arrives at i and misses everything: 1 for a node that is tested itself; chain[i] = the first box tested on
+    // arrival at i is i's own box or equal to it.
+    uint32_t nOut = 0;
+    for (uint32_t i = n; i-- > 0;) {
+        out_[i] = 0;
+        frontier[i] = 1;
+        chain[i] = 1;
+        if (!(leafWord[i] & kInnerBit))
+            continue;
+        const uint32_t c1 = i + 1u, c2 = leafWord[i] & ~kInnerBit;
+        const bool viaChain = sameBox[i] && chain[c1];
+        const uint32_t afterMiss = viaChain ? 1u : uint32_t(frontier[c1]) + frontier[c2];
+        const uint64_t v = visits[i], h = hits[i];
+        if (v > 0 && (v - h) * afterMiss < v && afterMiss < 60000u) {
+            out_[i] = 1;
+            frontier[i] = uint16_t(afterMiss);
+            chain[i] = viaChain ? 1 : 0;
+            nOut++;
+        }
+    }
+    // Top-down: where a miss of node i leads (before nodes left out are skipped): its escape link, or that of the
+    // node above whose place it takes (same box, first thing tested there).
+    escTo[0] = n;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!(leafWord[i] & kInnerBit))
+            continue;
+        const uint32_t c1 = i + 1u, c2 = leafWord[i] & ~kInnerBit;
+        escTo[c1] = (out_[i] && sameBox[i] && chain[c1]) ? escTo[i] : esc[c1];
+        escTo[c2] = esc[c2];
+    }
+    auto resolve = [&](uint32_t t) {
+        while (t < n && out_[t])
+            t++; // (a node left out is an inner node: its first child follows it)
+        return t;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const bool inner = (leafWord[i] & kInnerBit) != 0;
+        pruned[i] = make_uint2(resolve(escTo[i]) | (inner ? 0u : (leafWord[i] + 1u) << 16),
+                               inner ? resolve(i + 1u) : (kLeafDue | resolve(esc[i])));
+    }
+    pruned[n] = make_uint2(resolve(0u), nOut);
+}
+
+} // namespace
+
+// Make the link table for the tree the scene has now (the caller holds the scene's lock; `time` = a moment at which
+// moving surfaces are looked at).  Scenes that are not traced from LDS have none.
+int ptWavefrontBuildWalkLinks(pt_scene* scene, float time, hipStream_t stream)
+{
+    scene->dev.walkLinks = nullptr;
+    const uint32_t n = scene->dev.n_nodes;
+    if (n == 0 || n > kWalkLinkNodes || n >= 0xFFFFu || scene->dev.n_surfaces > kWalkLinkNodes / 2
+        || (size_t(2) * n + size_t(3) * scene->dev.n_surfaces) * 16 > kLdsGeoLimit)
+        return PT_OK;
+    if (!scene->walkLinks) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (2 * size_t(scene->n_surfaces) + 1) * sizeof(uint2)));
+        scene->owned.push_back(p);
+        scene->walkLinks = static_cast<uint2*>(p);
+    }
+    hipLaunchKernelGGL(walkLinksKernel, dim3(1), dim3(1024), 0, stream, scene->dev, time, scene->walkLinks);
+    HIP_TRY(hipGetLastError());
+    scene->dev.walkLinks = scene->walkLinks;
+    return PT_OK;
+}
+
+namespace {
+
 // the tracing step of one iteration
 template <bool DYN, bool LDS, bool STATS>
 void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_t stream, int parity)
@@ -1775,6 +1998,10 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
     uint32_t slotWaves, shadowWaves;
     traceWavesOf(pool.nSlots, slotWaves, shadowWaves);
     const size_t lds = LDS ? ldsTableBytes(sc) : 0;
+    // (PT_NO_WALK_PRUNE: the walk from LDS visits every node of the tree below the root, as the reference's does)
+    DevScene dv = sc->dev;
+    if (std::getenv("PT_NO_WALK_PRUNE") != nullptr)
+        dv.walkLinks = nullptr;
     // scenes in memory: nearer child first, then the few rays that leaves open in storage order
     const char* traversal = std::getenv("PT_TRAVERSAL");
     const bool referenceOrder = traversal && std::strcmp(traversal, "reference") == 0;
@@ -1813,7 +2040,7 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
             const uint32_t heldOct = uint32_t(sc->computeUnits) * std::min<uint32_t>(32u / (kOctantBlock / 64u), uint32_t((160u * 1024u) / octLds));
             const bool takenOct = takenRuns && heldOct < blocks;
             hipLaunchKernelGGL((traceKernel<false, LDS && !DYN, STATS, kOctantBlock, LDS && !DYN>), dim3(takenOct ? heldOct : blocks), dim3(kOctantBlock),
-                               octLds, stream, sc->dev, pool, w.counters, parity, w.samples, shadowCap, slotWaves, takenOct ? 1 : 0, stats);
+                               octLds, stream, dv, pool, w.counters, parity, w.samples, shadowCap, slotWaves, takenOct ? 1 : 0, stats);
             sc->kt.end(stream);
             return;
         }
@@ -1825,9 +2052,9 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         const bool taken = (takenRuns || (DYN && !fixedRuns)) && held < allBlocks;
         if (waveBlocks)
             hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS, (LDS && !DYN) ? 64u : 256u>), dim3(taken ? held : allBlocks), dim3(64), lds, stream,
-                               sc->dev, pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
+                               dv, pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         else
-            hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS, 256u>), dim3(taken ? held : allBlocks), dim3(256), lds, stream, sc->dev, pool,
+            hipLaunchKernelGGL((traceKernel<DYN, LDS, STATS, 256u>), dim3(taken ? held : allBlocks), dim3(256), lds, stream, dv, pool,
                                w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
     }

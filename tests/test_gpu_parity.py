@@ -262,21 +262,34 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
         return c
 
     root_misses = None
-    for env in ({}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}):
+    rows_of_every_node = None
+    # (PT_NO_WALK_PRUNE: the walk from LDS with every node of the tree in it)
+    for env in ({"PT_NO_WALK_PRUNE": "1"}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}):
+        in_lds = "PT_NO_LDS_SCENE" not in env
         c = counted(PT_TRACE_NULL_SHADOW_RAYS="1", **env)
         root_misses = ref["rays"] - (c["path_rays"] + c["shadow_rays"])
         assert 0 <= root_misses <= 64 * 48 * 9
         # (the walk from LDS does not test the root's box: a ray that misses it misses both children as well, which
         # are two visits where the reference has one -- a handful of rays that leave the open box near its rim)
-        root_tests = 0 if env else c["path_rays"] + c["shadow_rays"]
+        root_tests = c["path_rays"] + c["shadow_rays"] if in_lds else 0
         extra = c["box_rows"] + root_misses + root_tests - ref["node_visits"]
-        assert extra % 2 == 0 and 0 <= extra <= (0 if env else 64), (env, extra)
+        assert extra % 2 == 0 and 0 <= extra <= (64 if in_lds else 0), (env, extra)
+        if in_lds:
+            rows_of_every_node = c["box_rows"]
         assert c["surface_tests"] == ref["leaf_tests"], env
         assert c["retry_rays"] == 0 and c["leaf_rows"] == 0 and c["null_shadow_rays"] == 0
         d = counted(**env)
         assert d["path_rays"] == c["path_rays"]
         assert d["null_shadow_rays"] > 0 and d["shadow_rays"] + d["null_shadow_rays"] == c["shadow_rays"], env
         assert d["box_rows"] < c["box_rows"] and d["surface_tests"] < c["surface_tests"]
+    # The walk from LDS by default: inner nodes whose boxes most rays hit are left out of it (link table made with
+    # the tree).  Fewer box tests, and exactly the reference's surface tests: a leaf's own box is still tested, and a
+    # ray that misses a box that was left out misses every box inside it.
+    c = counted(PT_TRACE_NULL_SHADOW_RAYS="1")
+    assert c["path_rays"] + c["shadow_rays"] + root_misses == ref["rays"]
+    assert c["surface_tests"] == ref["leaf_tests"]
+    assert 0 < c["box_rows"] < rows_of_every_node
+    print("box tests of the walk from LDS: %d with every node, %d with the link table" % (rows_of_every_node, c["box_rows"]))
     c = counted(PT_NO_LDS_SCENE="1", PT_TRACE_NULL_SHADOW_RAYS="1")
     assert c["path_rays"] + c["shadow_rays"] + root_misses == ref["rays"]
     assert 0 < c["box_rows"] < ref["node_visits"]
@@ -291,7 +304,8 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
 def test_tracing_kernel_variants_of_a_small_scene(golden_dir, oracle):
     """The walks a small static scene can be traced with give the oracle's samples bit for bit: node table held
     eight-fold in LDS (one copy per combination of direction signs, the default for a few dozen nodes), held once
-    (PT_NO_OCTANT_ROWS), left in memory in storage order and nearer child first; each with the shadow rays that can
+    (PT_NO_OCTANT_ROWS), either with every node in the walk (PT_NO_WALK_PRUNE) or with the link table that leaves
+    often-hit inner nodes out, left in memory in storage order and nearer child first; each with the shadow rays that can
     only add zeros dropped (default) and traced (PT_TRACE_NULL_SHADOW_RAYS), and with the last paths of the batch
     left to the iterations (PT_FINISH_PATHS=0) or all paths finished by the one-lane-per-path kernel as soon as the
     last one has been started; on the tree of the file and on the device-built one (whose root is not the file's:
@@ -310,7 +324,8 @@ def test_tracing_kernel_variants_of_a_small_scene(golden_dir, oracle):
                 scene.nodes = dev.get_bvh()
                 d = scene.desc()
                 want = oracle.render_samples(C.byref(d), cam, p, math_mode=1)
-            for walk in ({}, {"PT_NO_OCTANT_ROWS": "1"}, {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}, {"PT_NO_LDS_SCENE": "1"}):
+            for walk in ({}, {"PT_NO_OCTANT_ROWS": "1"}, {"PT_NO_WALK_PRUNE": "1"}, {"PT_NO_WALK_PRUNE": "1", "PT_NO_OCTANT_ROWS": "1"},
+                         {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}, {"PT_NO_LDS_SCENE": "1"}):
                 for rays in ({}, {"PT_TRACE_NULL_SHADOW_RAYS": "1"}, {"PT_FINISH_PATHS": "0"}, {"PT_FINISH_PATHS": "100000000"}):
                     env = dict(walk, **rays)
                     os.environ.update(env)
