@@ -282,7 +282,7 @@ int pt_render(pt_scene* scene, const pt_camera* camera, const pt_render_params* 
  * non-blocking call: while paths are in flight the host reads the path
  * counters back every few iterations (hipStreamSynchronize on `hip_stream`)
  * to learn when the batch has drained, so it cannot be captured into a graph.
- * max_path_segments is at most 65535 (PT_ERR_LIMIT beyond). */
+ * max_path_segments is at most 4095 (PT_ERR_LIMIT beyond; the reference stops at 128). */
 int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                      float* d_out_rgb, void* hip_stream);
 

@@ -324,9 +324,10 @@ int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_
         return fail(PT_ERR_INVALID_ARGUMENT, "sample range outside [0, sqrt_spp^2]");
     if (scene->dev.n_nodes == 0)
         return fail(PT_ERR_INVALID_ARGUMENT, "scene has no acceleration structure yet (pt_scene_build_bvh_device or pt_scene_update_bvh)");
-    // (the path records keep the segment number in 16 bits)
-    if (p->max_path_segments > 65535)
-        return fail(PT_ERR_LIMIT, "max_path_segments above 65535");
+    // (the path records keep the segment number in 12 bits and the number of random draws, at most eight per
+    // segment, in 16; the reference stops at 128 segments)
+    if (p->max_path_segments > 4095)
+        return fail(PT_ERR_LIMIT, "max_path_segments above 4095");
     if (camera->has_animation
         && (camera->animation.type < PT_ANIM_IDENTITY || camera->animation.type > PT_ANIM_TWOKEY))
         return fail(PT_ERR_UNSUPPORTED, "camera animation has an unknown type");

@@ -10,23 +10,23 @@
 //   Kernel + trace-   reaches the chosen light, the prepared contribution is added
 //   RetryKernel)      (reference src/15/pathtracer.cpp:99-107);
 //   classifyKernel    puts the records whose ray hit a surface on a hit list and finishes
-//                     the ones whose ray left the scene: environment, radiance to the
-//                     sample buffer (reference src/15/pathtracer.cpp:60-62);
+//                     the ones whose ray left the scene: environment added to the path's
+//                     sample (reference src/15/pathtracer.cpp:60-62);
 //   shadeHitsKernel   per hit: hit record, scatter, emission, light pdfs, light sample,
 //                     MIS, Russian roulette (reference src/15/pathtracer.cpp:63-126);
 //                     queues the shadow ray; a path that goes on is written densely
-//                     into the other pool, a path that ends writes its radiance to
-//                     the sample buffer;
+//                     into the other pool;
 //   generateKernel    fills the rest of the other pool with new paths: path number,
 //                     camera ray, fresh path state
 //                     (reference src/15/pathtracer.cpp:202-215, camera.hpp:34-55);
 //
-// and then the pools change roles.  Finished radiances go to a sample buffer indexed
-// [sample][pixel]; resolveKernel then adds each pixel's samples in sample order --
-// the same sequence of float additions as the reference's accumulation loop
-// (src/15/pathtracer.cpp:207-220), which keeps the image bit-identical to a
-// sequential evaluation however the paths were scheduled.  All arithmetic per path
-// is that of pt_device.hpp.
+// and then the pools change roles.  A path's radiance lives in its place of a sample buffer
+// indexed [sample][pixel] from the start: emission, shadow-ray contributions and the
+// environment are added there in the order the reference adds them.  resolveKernel then adds
+// each pixel's samples in sample order -- the same sequence of float additions as the
+// reference's accumulation loop (src/15/pathtracer.cpp:207-220), which keeps the image
+// bit-identical to a sequential evaluation however the paths were scheduled.  All arithmetic
+// per path is that of pt_device.hpp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -46,7 +46,6 @@ namespace {
 enum : uint32_t { kEmpty = 0, kActive = 1 }; // state of a record: no path / a path with a ray to trace
 enum : uint8_t { kClsEmpty = 0, kClsMiss = 1, kClsHit = 2 }; // a hit is kClsHit + the type of the surface's material
 constexpr uint32_t kHitClasses = 8;
-constexpr uint32_t kDestIsSample = 0x80000000u;
 constexpr uint32_t kBackEmits = 0x40000000u;
 constexpr uint32_t kLightMask = 0x3FFFFFFFu;
 constexpr uint32_t kRetryIsShadow = 0x80000000u; // retry list entry: a shadow-queue entry rather than a slot
@@ -57,17 +56,20 @@ constexpr uint32_t kRetryFullWalk = 0x80000000u; // second word of the entry: th
 
 struct Pool {
     float4* o_t;   // ray origin, time
-    float4* d_s;   // ray direction, bits: state << 16 | segment
+    float4* d_s;   // ray direction, bits: random draws made << 16 | state << 12 | segment (stateWord)
     uint4* hit;    // surface | backside << 31, bits a, bits u, bits v
-    float4* thr_n; // throughput, bits: number of random draws made
-    float4* rad_p; // radiance so far, bits: index of the path in the sample buffer
+    float4* thr_p; // throughput, bits: index of the path in the sample buffer -- where its radiance so far lives: what
+                   // a path gathers (emission at a hit, a shadow ray's contribution, the environment) is added to
+                   // its sample in place, in the order the reference adds it, so radiance does not travel with the
+                   // record (a sample that is never added to keeps the +0 its path started with, and x + (+-0) = x
+                   // for every sum that began at +0)
     uint2* key;    // generator key of the path
     uint8_t* cls;  // what the tracing found for the record: kClsEmpty / kClsMiss / kClsHit + class (classifyKernel reads
                    // only this byte per record)
     float4* sh_o;  // shadow ray queue: origin, time
-    float4* sh_d;  //   direction, bits: destination (record of the pool traced next, or sample-buffer index)
+    float4* sh_d;  //   direction, bits: sample-buffer index of the path
     float4* sh_c;  //   what to add if the ray reaches the front side of the chosen light, bits: light
-                   //   surface | kBackEmits | kDestIsSample
+                   //   surface | kBackEmits
     float4* sh_b;  //   what to add if it reaches the back side (only written when kBackEmits)
     uint2* retry;  // rays to trace again in storage order: (slot, or kRetryIsShadow | shadow-queue entry; bits of
                    // the distance beyond which nothing needs to be looked at), kRetryShards sub-lists
@@ -136,6 +138,26 @@ constexpr uint32_t kCtrWords = (kCtrWork + 2 * kShards) * kCtrStride;
 
 PT_DEV uint32_t laneId() { return __lane_id(); }
 
+// A sample = three floats at a 4-byte-aligned place of the sample buffer, moved with one 12-byte access.
+struct __attribute__((packed, aligned(4))) Sample3 {
+    float x, y, z;
+};
+PT_DEV V3 loadSample(const float* samples, size_t index)
+{
+    const Sample3 v = *reinterpret_cast<const Sample3*>(samples + 3 * index);
+    return v3(v.x, v.y, v.z);
+}
+PT_DEV void storeSample(float* samples, size_t index, V3 v)
+{
+    *reinterpret_cast<Sample3*>(samples + 3 * index) = Sample3{ v.x, v.y, v.z };
+}
+
+// last word of a record's direction row: segments below 4096 (checkRender), at most eight draws per segment
+PT_DEV uint32_t stateWord(uint32_t state, uint32_t segment, uint32_t draws) { return draws << 16 | state << 12 | segment; }
+PT_DEV uint32_t stateOf(uint32_t w) { return (w >> 12) & 3u; }
+PT_DEV uint32_t segmentOf(uint32_t w) { return w & 0xFFFu; }
+PT_DEV uint32_t drawsOf(uint32_t w) { return w >> 16; }
+
 // (the count of path numbers handed out by a shard keeps growing while a batch drains, a region's worth per iteration:
 // it must stop at the top rather than start again)
 PT_DEV uint32_t addSaturating(uint32_t a, uint32_t b) { return a > 0xFFFFFFFFu - b ? 0xFFFFFFFFu : a + b; }
@@ -181,13 +203,13 @@ PT_DEV void blockReserve2(uint32_t* counterA, bool wantA, uint32_t* counterB, bo
 }
 
 // A shadow ray has found its closest hit: if that is the chosen light, add the prepared
-// contribution to the path's radiance or to its finished sample (reference
+// contribution to the path's sample (reference
 // src/15/pathtracer.cpp:102-107).  Which side of the light: triangles know from the hit test,
 // spheres from the hit point (reference src/15/surface_sphere.hpp:29-34).
 template <bool DYN>
 PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, const Pool& pool, float* __restrict__ samples,
                          uint32_t entry, const Ray& ray, const HitLite& best, float4 payload, uint32_t dest,
-                         uint32_t destW, V3 destValue)
+                         V3 destValue)
 {
     if (best.sid == PT_NO_HIT || best.sid != (fbits(payload.w) & kLightMask))
         return;
@@ -211,15 +233,7 @@ PT_DEV void shadowArrive(const DevScene& sc, const float4* __restrict__ surf, co
         const float4 pb = pool.sh_b[entry];
         add = v3(pb.x, pb.y, pb.z);
     }
-    V3 sum = destValue + add;
-    if (fbits(payload.w) & kDestIsSample) {
-        float* p = samples + 3 * size_t(dest);
-        p[0] = sum.x;
-        p[1] = sum.y;
-        p[2] = sum.z;
-    } else {
-        pool.rad_p[dest] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(destW));
-    }
+    storeSample(samples, dest, destValue + add);
 }
 
 // Closest-hit tracing of a stream of rays.  Every wave owns a contiguous run of
@@ -505,7 +519,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
     // shadow rays: what to add on arrival, where, and the current value there
     float4 payload = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     V3 destValue = v3(0.0f);
-    uint32_t dest = 0, destW = 0;
+    uint32_t dest = 0;
 
     for (;;) {
         const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
@@ -532,7 +546,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                 item = cand;
                 if (!shadow) {
                     const float4 d_s = pool.d_s[item];
-                    if (((fbits(d_s.w) >> 16) & 3u) == kActive) {
+                    if (stateOf(fbits(d_s.w)) == kActive) {
                         const float4 o_t = pool.o_t[item];
                         ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
                         have = true;
@@ -541,14 +555,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                     const float4 so = pool.sh_o[item], sd = pool.sh_d[item];
                     payload = pool.sh_c[item];
                     dest = fbits(sd.w);
-                    if (fbits(payload.w) & kDestIsSample) {
-                        const float* p = samples + 3 * size_t(dest);
-                        destValue = v3(p[0], p[1], p[2]);
-                    } else {
-                        const float4 r = pool.rad_p[dest];
-                        destValue = v3(r.x, r.y, r.z);
-                        destW = fbits(r.w);
-                    }
+                    destValue = loadSample(samples, dest);
                     ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
                     have = true;
                 }
@@ -630,7 +637,7 @@ __global__ void __launch_bounds__(BLOCK) traceKernel(DevScene sc, Pool pool, uin
                                             fbits(best.a), fbits(best.u), fbits(best.v));
                 pool.cls[item] = best.sid == PT_NO_HIT ? uint8_t(kClsMiss) : uint8_t(kClsHit + best.matClass);
             } else {
-                shadowArrive<DYN>(sc, surf, pool, samples, item, ray, best, payload, dest, destW, destValue);
+                shadowArrive<DYN>(sc, surf, pool, samples, item, ray, best, payload, dest, destValue);
             }
         }
     }
@@ -787,7 +794,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                 item = cand;
                 if (!shadow) {
                     const float4 d_s = pool.d_s[item];
-                    if (((fbits(d_s.w) >> 16) & 3u) == kActive) {
+                    if (stateOf(fbits(d_s.w)) == kActive) {
                         const float4 o_t = pool.o_t[item];
                         ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
                         have = true;
@@ -1024,17 +1031,8 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                 const float4 payload = pool.sh_c[item];
                 if (best.sid == (fbits(payload.w) & kLightMask)) {
                     const uint32_t dest = fbits(pool.sh_d[item].w);
-                    V3 destValue;
-                    uint32_t destW = 0;
-                    if (fbits(payload.w) & kDestIsSample) {
-                        const float* p = samples + 3 * size_t(dest);
-                        destValue = v3(p[0], p[1], p[2]);
-                    } else {
-                        const float4 r = pool.rad_p[dest];
-                        destValue = v3(r.x, r.y, r.z);
-                        destW = fbits(r.w);
-                    }
-                    shadowArrive<DYN>(sc, surf, pool, samples, item, ray, best, payload, dest, destW, destValue);
+                    const V3 destValue = loadSample(samples, dest);
+                    shadowArrive<DYN>(sc, surf, pool, samples, item, ray, best, payload, dest, destValue);
                 }
             }
         }
@@ -1087,19 +1085,10 @@ __global__ void __launch_bounds__(256) traceRetryKernel(DevScene sc, Pool pool, 
             const uint32_t q = e & ~kRetryIsShadow;
             const float4 so = pool.sh_o[q], sd = pool.sh_d[q], payload = pool.sh_c[q];
             const uint32_t dest = fbits(sd.w);
-            V3 destValue;
-            uint32_t destW = 0;
-            if (fbits(payload.w) & kDestIsSample) {
-                const float* p = samples + 3 * size_t(dest);
-                destValue = v3(p[0], p[1], p[2]);
-            } else {
-                const float4 r = pool.rad_p[dest];
-                destValue = v3(r.x, r.y, r.z);
-                destW = fbits(r.w);
-            }
+            const V3 destValue = loadSample(samples, dest);
             const Ray ray = makeRay(v3(so.x, so.y, so.z), v3(sd.x, sd.y, sd.z), so.w);
             const HitLite best = closestHitFrom<STATS, DYN>(sc, ray, 0.0001f, boxAmin, bound, &cnt);
-            shadowArrive<DYN>(sc, sc.surf, pool, samples, q, ray, best, payload, dest, destW, destValue);
+            shadowArrive<DYN>(sc, sc.surf, pool, samples, q, ray, best, payload, dest, destValue);
         }
     }
     addStats<STATS>(stats, kStatRetryNodes, cnt.nodeVisits);
@@ -1239,20 +1228,8 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     }
     static_assert(kClassifyChunks <= 8, "one byte per run in `misses`");
     // the rays that left the scene (reference src/15/pathtracer.cpp:60-62): add the environment, done
-    if (sc.envmap.type == PT_ENV_NONE) {
-        // (nothing to add: radiance so far is the sample)
-#pragma unroll 1
-        for (uint32_t j = 0; j < kClassifyChunks; j++) {
-            if ((misses >> (8 * j)) & 1u) {
-                const float4 rad_p = pool.rad_p[slot0 + j * kClassifyBlock];
-                float* p = samples + 3 * size_t(fbits(rad_p.w));
-                p[0] = rad_p.x;
-                p[1] = rad_p.y;
-                p[2] = rad_p.z;
-            }
-        }
-        return;
-    }
+    if (sc.envmap.type == PT_ENV_NONE)
+        return; // (nothing to add: the path's sample holds its radiance already)
     // The environment's value is a few hundred instructions (two inverse trigonometric functions in double
     // precision, a texture lookup), and a quarter of the records or fewer are misses: each wave first collects its
     // misses in LDS and then works them off with all lanes.
@@ -1270,12 +1247,9 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
 #pragma unroll 1
     for (uint32_t i = lane; i < nMisses; i += 64u) {
         const uint32_t slot = missSlots[wave][i];
-        const float4 rad_p = pool.rad_p[slot], thr_n = pool.thr_n[slot], d_s = pool.d_s[slot];
-        const V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z) + v3(thr_n.x, thr_n.y, thr_n.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z));
-        float* p = samples + 3 * size_t(fbits(rad_p.w));
-        p[0] = radiance.x;
-        p[1] = radiance.y;
-        p[2] = radiance.z;
+        const float4 thr_p = pool.thr_p[slot], d_s = pool.d_s[slot];
+        storeSample(samples, fbits(thr_p.w),
+                    loadSample(samples, fbits(thr_p.w)) + v3(thr_p.x, thr_p.y, thr_p.z) * envmapValue(sc, v3(d_s.x, d_s.y, d_s.z)));
     }
 }
 
@@ -1303,24 +1277,22 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
     float shTime = 0.0f;
     uint32_t shLight = 0;
     uint32_t pathLocal = 0;
-    float4 nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nD = nO, nT = nO, nR = nO;
+    float4 nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nD = nO, nT = nO;
     uint2 kw = make_uint2(0u, 0u);
 
     if (valid) {
         const float4 d_s = pool.d_s[slot];
         const float4 o_t = pool.o_t[slot];
-        const float4 thr_n = pool.thr_n[slot];
-        const float4 rad_p = pool.rad_p[slot];
+        const float4 thr_p = pool.thr_p[slot];
         const uint4 hw = pool.hit[slot];
         kw = pool.key[slot];
-        const int segment = int(fbits(d_s.w) & 0xFFFFu);
+        const int segment = int(segmentOf(fbits(d_s.w)));
         Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
-        V3 throughput = v3(thr_n.x, thr_n.y, thr_n.z);
-        V3 radiance = v3(rad_p.x, rad_p.y, rad_p.z);
-        pathLocal = fbits(rad_p.w);
+        V3 throughput = v3(thr_p.x, thr_p.y, thr_p.z);
+        pathLocal = fbits(thr_p.w);
         Rng<false> rng;
         rng.key = uint64_t(kw.x) | (uint64_t(kw.y) << 32);
-        rng.n = fbits(thr_n.w);
+        rng.n = drawsOf(fbits(d_s.w));
         rng.cnt = nullptr;
 
         // one turn of the loop of pathSample for a hit, reference src/15/pathtracer.cpp:63-127
@@ -1333,7 +1305,17 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
         Hit hr = makeHit(sc, ray, hl);
         MaterialValues mv;
         Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng, &mv);
-        radiance = radiance + throughput * materialLe(sc, hr.material, hr.backside);
+        {
+            // radiance += throughput * Le, on the path's sample: nothing to do for a surface that does not emit --
+            // unless the throughput is no longer finite, when 0 * throughput is NaN and the reference's sum becomes NaN
+            const V3 le = materialLe(sc, hr.material, hr.backside);
+            const bool emits = le.x != 0.0f || le.y != 0.0f || le.z != 0.0f;
+            const bool finite = fabs_(throughput.x) < __builtin_huge_valf() && fabs_(throughput.y) < __builtin_huge_valf()
+                && fabs_(throughput.z) < __builtin_huge_valf();
+            if (emits || !finite) {
+                storeSample(samples, pathLocal, loadSample(samples, pathLocal) + throughput * le);
+            }
+        }
         if (sr.type == ScatterNone) {
             finished = true;
         } else {
@@ -1408,17 +1390,11 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
             if (segment + 1 >= pp.maxSegments)
                 finished = true;
         }
-        if (finished) {
-            float* p = samples + 3 * size_t(pathLocal);
-            p[0] = radiance.x;
-            p[1] = radiance.y;
-            p[2] = radiance.z;
-        } else {
+        if (!finished) {
             nO = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
             nD = make_float4(ray.direction.x, ray.direction.y, ray.direction.z,
-                             __uint_as_float((kActive << 16) | uint32_t(segment + 1)));
-            nT = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng.n));
-            nR = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(pathLocal));
+                             __uint_as_float(stateWord(kActive, uint32_t(segment + 1), rng.n)));
+            nT = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(pathLocal));
         }
     }
 
@@ -1437,15 +1413,14 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
     if (goesOn) {
         next.o_t[place] = nO;
         next.d_s[place] = nD;
-        next.thr_n[place] = nT;
-        next.rad_p[place] = nR;
+        next.thr_p[place] = nT;
         next.key[place] = kw;
     }
     if (haveShadow) {
         const uint32_t e = shard * shadowCap + pos;
         pool.sh_o[e] = make_float4(shOrigin.x, shOrigin.y, shOrigin.z, shTime);
-        pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(finished ? pathLocal : place));
-        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight | (finished ? kDestIsSample : 0u)));
+        pool.sh_d[e] = make_float4(shDir.x, shDir.y, shDir.z, __uint_as_float(pathLocal));
+        pool.sh_c[e] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(shLight));
         if (shLight & kBackEmits)
             pool.sh_b[e] = make_float4(shBack.x, shBack.y, shBack.z, 0.0f);
     }
@@ -1466,16 +1441,15 @@ __global__ void __launch_bounds__(64) finishPathsKernel(DevScene sc, Pool pool, 
         return;
     const uint32_t slot = region * (pool.nSlots / kShards) + inRegion;
     const float4 d_s = pool.d_s[slot];
-    if (((fbits(d_s.w) >> 16) & 3u) != kActive)
+    if (stateOf(fbits(d_s.w)) != kActive)
         return;
     const float4 o_t = pool.o_t[slot];
-    const float4 thr_n = pool.thr_n[slot];
-    const float4 rad_p = pool.rad_p[slot];
+    const float4 thr_p = pool.thr_p[slot];
     const uint4 hw = pool.hit[slot];
     const uint2 kw = pool.key[slot];
     Rng<false> rng;
     rng.key = uint64_t(kw.x) | (uint64_t(kw.y) << 32);
-    rng.n = fbits(thr_n.w);
+    rng.n = drawsOf(fbits(d_s.w));
     rng.cnt = nullptr;
     HitLite hl = noHit();
     if (hw.x != PT_NO_HIT) {
@@ -1486,12 +1460,10 @@ __global__ void __launch_bounds__(64) finishPathsKernel(DevScene sc, Pool pool, 
         hl.v = __uint_as_float(hw.w);
     }
     const Ray ray = makeRay(v3(o_t.x, o_t.y, o_t.z), v3(d_s.x, d_s.y, d_s.z), o_t.w);
-    const V3 radiance = pathSampleFrom<false>(sc, pp, ray, rng, nullptr, int(fbits(d_s.w) & 0xFFFFu), v3(rad_p.x, rad_p.y, rad_p.z),
-                                              v3(thr_n.x, thr_n.y, thr_n.z), true, hl);
-    float* p = samples + 3 * size_t(fbits(rad_p.w));
-    p[0] = radiance.x;
-    p[1] = radiance.y;
-    p[2] = radiance.z;
+    const V3 radiance = pathSampleFrom<false>(sc, pp, ray, rng, nullptr, int(segmentOf(fbits(d_s.w))),
+                                              loadSample(samples, fbits(thr_p.w)) /* the path's radiance so far */,
+                                              v3(thr_p.x, thr_p.y, thr_p.z), true, hl);
+    storeSample(samples, fbits(thr_p.w), radiance);
 }
 
 // `next` = the pool being filled: the places of every region behind the paths that go on
@@ -1535,7 +1507,7 @@ __global__ void __launch_bounds__(256) generateKernel(DevScene sc, Pool next, Re
     const int ly = int(tileRow * 8u + (inTile >> 3));
     if (group >= b.totalIds >> 6 || lx >= a.tw || ly >= a.th) {
         // no paths left, or padding of an edge tile: the place stays empty in this iteration
-        next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
+        next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(stateWord(kEmpty, 0u, 0u)));
         next.cls[place] = kClsEmpty;
         return;
     }
@@ -1562,42 +1534,47 @@ __global__ void __launch_bounds__(256) generateKernel(DevScene sc, Pool next, Re
             V3 radiance = v3(0.0f);
             if (sc.envmap.type != PT_ENV_NONE)
                 radiance = radiance + v3(1.0f) * envmapValue(sc, ray.direction);
-            float* out = samples + 3 * size_t(sLocal * b.npix + uint32_t(ly * a.tw + lx));
-            out[0] = radiance.x;
-            out[1] = radiance.y;
-            out[2] = radiance.z;
-            next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
+            storeSample(samples, group * 64u + inTile, radiance);
+            next.d_s[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(stateWord(kEmpty, 0u, 0u)));
             next.cls[place] = kClsEmpty;
             return;
         }
     }
 #endif
     next.o_t[place] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.time);
-    next.d_s[place] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(kActive << 16));
-    next.thr_n[place] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n));
-    next.rad_p[place] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(sLocal * b.npix + uint32_t(ly * a.tw + lx)));
+    // A path's place in the sample buffer is its number: the paths under way at any time are a window of
+    // consecutive numbers, so what the kernels add to samples stays within a few hundred megabytes of the buffer
+    // (tile by tile, and within a tile sample by sample: [tile][sample][pixel of the tile]).
+    const uint32_t pathLocal = group * 64u + inTile;
+    next.d_s[place] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, __uint_as_float(stateWord(kActive, 0u, rng.n)));
+    next.thr_p[place] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pathLocal));
+    storeSample(samples, pathLocal, v3(0.0f)); // radiance so far: none
     next.key[place] = make_uint2(uint32_t(rng.key), uint32_t(rng.key >> 32));
 }
 
-// Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).
+// Add the samples of every pixel in sample order (reference src/15/pathtracer.cpp:207-220).  The sample buffer is
+// ordered [tile][sample][pixel of the 8x8 tile] (see generateKernel): a wave takes a tile.
 __global__ void __launch_bounds__(256) resolveKernel(const float* __restrict__ samples, float* __restrict__ accum,
                                                      float* __restrict__ out, RenderArgs a, Batch b, int firstBatch,
                                                      int lastBatch)
 {
-    const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
-    if (pix >= b.npix)
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), inTile = threadIdx.x & 63u;
+    if (tile >= b.tilesX * b.tilesY)
         return;
+    const uint32_t tileRow = b.byTilesX.div(tile);
+    const int lx = int((tile - tileRow * b.tilesX) * 8u + (inTile & 7u)), ly = int(tileRow * 8u + (inTile >> 3));
+    if (lx >= a.tw || ly >= a.th)
+        return;
+    const uint32_t pix = uint32_t(ly * a.tw + lx);
     V3 acc = v3(0.0f);
     if (!firstBatch)
         acc = v3(accum[3 * size_t(pix) + 0], accum[3 * size_t(pix) + 1], accum[3 * size_t(pix) + 2]);
-    for (uint32_t s = 0; s < b.nS; s++) {
-        const float* p = samples + 3 * (size_t(s) * b.npix + pix);
-        acc = acc + v3(p[0], p[1], p[2]);
-    }
+    for (uint32_t s = 0; s < b.nS; s++)
+        acc = acc + loadSample(samples, (size_t(tile) * b.nS + s) * 64u + inTile);
     if (lastBatch) {
         if (!(a.p.flags & PT_RENDER_SUM_ONLY))
             acc = acc / float(a.p.sqrt_spp * a.p.sqrt_spp);
-        const int x = a.x0 + int(pix % uint32_t(a.tw)), y = a.y0 + int(pix / uint32_t(a.tw));
+        const int x = a.x0 + lx, y = a.y0 + ly;
         float* o = out + 3 * (size_t(y) * a.p.width + x);
         o[0] = acc.x;
         o[1] = acc.y;
@@ -1619,9 +1596,9 @@ __global__ void __launch_bounds__(256) fillRaysKernel(Pool pool, uint64_t n, con
         pool.o_t[slot] = make_float4(origins[3 * size_t(slot) + 0], origins[3 * size_t(slot) + 1], origins[3 * size_t(slot) + 2],
                                      times ? times[slot] : 0.0f);
         pool.d_s[slot] = make_float4(dirs[3 * size_t(slot) + 0], dirs[3 * size_t(slot) + 1], dirs[3 * size_t(slot) + 2],
-                                     __uint_as_float(kActive << 16));
+                                     __uint_as_float(stateWord(kActive, 0u, 0u)));
     } else {
-        pool.d_s[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kEmpty << 16));
+        pool.d_s[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(stateWord(kEmpty, 0u, 0u)));
     }
     pool.cls[slot] = kClsEmpty;
 }
@@ -1691,7 +1668,7 @@ constexpr uint32_t retryCapOf(uint32_t nSlots)
 
 constexpr size_t poolBytes(uint32_t n)
 {
-    return 2 * size_t(n) * (16 * 5 + 8 + 1) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 4)
+    return 2 * size_t(n) * (16 * 4 + 8 + 1) + size_t(shadowCapOf(n)) * kShards * (16 * 4 + 4)
         + size_t(retryCapOf(n)) * kRetryShards * 8;
 }
 
@@ -1719,8 +1696,7 @@ void carvePools(void* base, uint32_t n, Pool pools[2])
         p.o_t = static_cast<float4*>(take(size_t(n) * 16));
         p.d_s = static_cast<float4*>(take(size_t(n) * 16));
         p.hit = static_cast<uint4*>(take(size_t(n) * 16));
-        p.thr_n = static_cast<float4*>(take(size_t(n) * 16));
-        p.rad_p = static_cast<float4*>(take(size_t(n) * 16));
+        p.thr_p = static_cast<float4*>(take(size_t(n) * 16));
         p.key = static_cast<uint2*>(take(size_t(n) * 8));
         p.cls = static_cast<uint8_t*>(take(size_t(n)));
         pools[k] = p;
@@ -2202,7 +2178,7 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
     const uint64_t idsPerSample = uint64_t(tilesX) * tilesY * 64u;
     // samples per batch: bounded by the sample-buffer budget and by 32-bit path numbers
     const uint64_t budgetBytes = w.fixed ? w.sampleCapacity * 12 : envU64("PT_SAMPLE_BUFFER_MB", 32768) << 20;
-    uint64_t perBatch = std::max<uint64_t>(1, budgetBytes / (npix * 12));
+    uint64_t perBatch = std::max<uint64_t>(1, budgetBytes / (idsPerSample * 12)); // (a sample per path number: whole tiles)
     perBatch = std::min<uint64_t>(perBatch, (0xFFFFFFFFull - (1ull << 24)) / idsPerSample);
     if (perBatch == 0)
         return fail(PT_ERR_LIMIT, "tile too large for the wavefront renderer");
@@ -2215,11 +2191,11 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
     nSlots = std::max<uint64_t>((nSlots + slotUnit - 1) / slotUnit * slotUnit, slotUnit);
     if (w.fixed) {
         // work areas of a fixed size (nothing is allocated here): the caller has checked the pixel count
-        if (nSlots > w.fixedSlots || poolBytes(uint32_t(nSlots)) > w.poolCapacity || npix * perBatch > w.sampleCapacity
+        if (nSlots > w.fixedSlots || poolBytes(uint32_t(nSlots)) > w.poolCapacity || idsPerSample * perBatch > w.sampleCapacity
             || npix > w.accumCapacity)
             return fail(PT_ERR_LIMIT, "render does not fit the fixed work area");
     } else {
-        int rc = ensureBuffers(sc, uint32_t(nSlots), npix * perBatch, npix);
+        int rc = ensureBuffers(sc, uint32_t(nSlots), idsPerSample * perBatch, npix);
         if (rc != PT_OK)
             return rc;
     }
@@ -2244,7 +2220,7 @@ int renderBatches(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, float*
             return rc;
         if (d_out) {
             sc->kt.begin(KernelTimes::kResolve, stream);
-            hipLaunchKernelGGL(resolveKernel, dim3((b.npix + 255u) / 256u), dim3(256), 0, stream, w.samples, w.accum,
+            hipLaunchKernelGGL(resolveKernel, dim3((tilesX * tilesY + 3u) / 4u), dim3(256), 0, stream, w.samples, w.accum,
                                d_out, a, b, s == 0 ? 1 : 0, s + b.nS >= nsTotal ? 1 : 0);
             sc->kt.end(stream);
             HIP_TRY(hipGetLastError());
@@ -2271,12 +2247,17 @@ int ptWavefrontSamples(pt_scene* scene, const RenderArgs& a, float* h_out)
         return rc;
     const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
     const uint64_t ns = uint64_t(a.s1 - a.s0);
-    std::vector<float> tmp(npix * ns * 3);
+    // the buffer is ordered [8x8 tile][sample][pixel of the tile]
+    const uint64_t tilesX = uint64_t(a.tw + 7) / 8u, tilesY = uint64_t(a.th + 7) / 8u;
+    std::vector<float> tmp(tilesX * tilesY * 64u * ns * 3);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tmp.data(), scene->wf.samples, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (uint64_t s = 0; s < ns; s++)
-        for (uint64_t p = 0; p < npix; p++)
-            std::memcpy(h_out + 3 * (p * ns + s), tmp.data() + 3 * (s * npix + p), 12);
+    for (uint64_t p = 0; p < npix; p++) {
+        const uint64_t lx = p % uint64_t(a.tw), ly = p / uint64_t(a.tw);
+        const uint64_t tile = (ly / 8u) * tilesX + lx / 8u, inTile = (ly % 8u) * 8u + lx % 8u;
+        for (uint64_t s = 0; s < ns; s++)
+            std::memcpy(h_out + 3 * (p * ns + s), tmp.data() + 3 * ((tile * ns + s) * 64u + inTile), 12);
+    }
     return PT_OK;
 }
 
@@ -2356,9 +2337,10 @@ int ptWavefrontStaticSetup(int device)
 
 int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream)
 {
-    const uint64_t npix = uint64_t(a.tw) * uint64_t(a.th);
+    // (the rectangle is worked on in 8x8 tiles, and samples are kept for whole tiles)
+    const uint64_t npix = (uint64_t(a.tw + 7) / 8u) * (uint64_t(a.th + 7) / 8u) * 64u;
     if (npix > kStaticMaxPixels)
-        return fail(PT_ERR_LIMIT, "pt_render_device_noalloc renders at most 524288 pixels per call (use tile rectangles)");
+        return fail(PT_ERR_LIMIT, "pt_render_device_noalloc renders at most 524288 pixels per call, counted in whole 8x8 tiles (use tile rectangles)");
     const int device = scene->device;
     int rc = ptWavefrontStaticSetup(device); // (a lookup in a table after the first call on this GPU)
     if (rc != PT_OK)
