@@ -295,16 +295,19 @@ int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_p
  * per GPU, held until the process ends.  The call makes no hipMalloc /
  * hipFree / hipHostMalloc and creates no events (per-kernel timing, see
  * pt_scene_profile, is off during it).
- * Limits: at most 524 288 pixels in the tile rectangle of one call
- * (PT_ERR_LIMIT beyond; render larger images tile by tile), any number of
- * samples (they are run in batches that fit the area).  The pools hold
- * 131 072 paths, an eighth of what pt_render_device uses by default, so this
- * entry point is slower on large renders.
- * All calls on one GPU share that GPU's copy of the area.  Calls on the same
- * scene are ordered by the library (see pt_scene_create).  Calls on different
- * scenes of one GPU that overlap race on the area: the caller has to order
- * them (same stream, or an event); a call that arrives while another call is
- * still enqueueing on that GPU fails with PT_ERR_INVALID_ARGUMENT. */
+ * Limits: at most 524 288 pixels in the tile rectangle of one call, counted
+ * in the whole 8 x 8 pixel tiles that cover it (PT_ERR_LIMIT beyond; render
+ * larger images tile by tile), any number of samples (they are run in batches
+ * that fit the area).  The pools hold 131 072 paths, a fraction of what
+ * pt_render_device uses by default, so this entry point is slower on large
+ * renders.
+ * All calls on one GPU share that GPU's copy of the area, whatever their
+ * scene and stream: the library orders them on the device -- every call
+ * makes its stream wait for an event that the previous call on that GPU
+ * recorded behind its last kernel (the event is created with the first scene
+ * on the GPU, not by the call).  Only a call that arrives while another
+ * thread is still inside a call on that GPU is refused, with
+ * PT_ERR_INVALID_ARGUMENT, rather than made to wait. */
 int pt_render_device_noalloc(pt_scene* scene, const pt_camera* camera, const pt_render_params* params,
                              float* d_out_rgb, void* hip_stream);
 
@@ -315,20 +318,41 @@ int pt_render_device_noalloc(pt_scene* scene, const pt_camera* camera, const pt_
  * different device numbers; two handles on one GPU are allowed) and
  * pt_render_multi renders `params` with one host thread per handle:
  *   PT_SHARD_TILES    256 x 256 tiles of the rectangle round robin over the
- *                     handles, gathered by peer copies into the first handle's
- *                     GPU: the image equals pt_render's bit for bit;
+ *                     handles, gathered into the first handle's GPU: the image
+ *                     equals pt_render's bit for bit;
  *   PT_SHARD_SAMPLES  contiguous ranges of the sample indices, partial sums
  *                     added on the first handle's GPU in handle order: equals
  *                     pt_render's image to rounding (another addition order).
- * out_rgb as for pt_render.  pt_multi_plan gives the render calls of share
- * `share` of `n_shares` (pure host code; call with capacity 0 for the count);
- * a distributed caller (one process per GPU) renders its share's calls with
- * pt_render_device and combines with a collective instead. */
+ * The first handle renders into the result; per other handle the combine is
+ * one asynchronous peer copy of the rectangle's rows (over xGMI where
+ * hipDeviceCanAccessPeer says so, which is then switched on; staged through
+ * the host by the runtime where not) and one kernel on the first handle's GPU.
+ * The work buffers are kept with the handles, so a call allocates only when
+ * the image is larger than any before.  (Cross-GPU copies have only been
+ * rehearsed with several handles on one GPU so far.)
+ * pt_render_multi: out_rgb as for pt_render (host memory).
+ * pt_render_multi_device: the result goes to d_out_rgb, a buffer of
+ * width*height*3 floats on the FIRST handle's GPU; the first handle's work and
+ * the combine are enqueued on hip_stream (a stream of that GPU, NULL = default
+ * stream), the call returns once everything is enqueued.  Pixels outside the
+ * rectangle are not touched by either.  One call at a time per first handle.
+ * pt_multi_last_combine: device time between the first handle's last render
+ * kernel and the end of the last combine on first_scene (waits for it), and
+ * what it consisted of: kernels launched, peer copies, and how many of those
+ * went between GPUs that can reach each other's memory (or within one GPU).
+ * pt_multi_plan gives the render calls of share `share` of `n_shares` (pure
+ * host code; call with capacity 0 for the count); a distributed caller (one
+ * process per GPU) renders its share's calls with pt_render_device and
+ * combines with a collective instead. */
 enum { PT_SHARD_TILES = 0, PT_SHARD_SAMPLES = 1 };
 int pt_multi_plan(const pt_render_params* params, int mode, int n_shares, int share, pt_render_params* out_calls,
                   int capacity, int* out_count);
 int pt_render_multi(pt_scene* const* scenes, int n_scenes, const pt_camera* camera, const pt_render_params* params,
                     int mode, float* out_rgb);
+int pt_render_multi_device(pt_scene* const* scenes, int n_scenes, const pt_camera* camera, const pt_render_params* params,
+                           int mode, float* d_out_rgb, void* hip_stream);
+int pt_multi_last_combine(pt_scene* first_scene, float* out_ms, int* out_kernel_launches, int* out_peer_copies,
+                          int* out_direct_copies);
 
 /* Closest hits of n caller-supplied rays: BVHTreeLinear::hit(ray, amin, amax)
  * (reference src/15/bvh.hpp:183-213) for each.  Host arrays: origins and

@@ -74,6 +74,10 @@ def lib():
                                     C.POINTER(abi.pt_render_params), C.c_int, C.POINTER(C.c_int)]
         L.pt_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(abi.pt_camera),
                                       C.POINTER(abi.pt_render_params), C.c_int, _fp]
+        L.pt_render_multi_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(abi.pt_camera),
+                                             C.POINTER(abi.pt_render_params), C.c_int, C.c_void_p, C.c_void_p]
+        L.pt_multi_last_combine.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int)]
         L.pt_render_counted.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp,
                                         C.POINTER(abi.pt_counters)]
         L.pt_render_samples.argtypes = [C.c_void_p, C.POINTER(abi.pt_camera), C.POINTER(abi.pt_render_params), _fp]
@@ -593,6 +597,20 @@ def render_multi(device_scenes, cam, params, mode=abi.PT_SHARD_TILES, out=None):
     handles = (C.c_void_p * len(device_scenes))(*[d.handle for d in device_scenes])
     _check(lib().pt_render_multi(handles, len(device_scenes), C.byref(cam), C.byref(params), mode, _f(out)))
     return out
+
+
+def render_multi_device(device_scenes, cam, params, d_out, mode=abi.PT_SHARD_TILES, stream=None):
+    """pt_render_multi_device: the image into device memory of the first handle's GPU (address d_out)."""
+    handles = (C.c_void_p * len(device_scenes))(*[d.handle for d in device_scenes])
+    _check(lib().pt_render_multi_device(handles, len(device_scenes), C.byref(cam), C.byref(params), mode, C.c_void_p(d_out),
+                                        C.c_void_p(stream or 0)))
+
+
+def multi_last_combine(first_scene):
+    """(milliseconds, kernel launches, peer copies, direct copies) of the last combine on the first handle."""
+    ms, k, c, d = C.c_float(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(lib().pt_multi_last_combine(first_scene.handle, C.byref(ms), C.byref(k), C.byref(c), C.byref(d)))
+    return ms.value, k.value, c.value, d.value
 
 
 class DeviceScene:

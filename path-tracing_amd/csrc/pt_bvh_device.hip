@@ -1261,12 +1261,13 @@ int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity,
 try {
     if (!scene || !out_count)
         return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    // (the count is read under the scene's lock: a rebuild in another thread keeps it at zero while it runs)
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
     const uint64_t n = scene->dev.n_nodes;
     *out_count = n;
     if (!out_nodes || capacity < n)
         return out_nodes ? fail(PT_ERR_INVALID_ARGUMENT, "node buffer too small") : PT_OK;
-    SceneCall call(scene, nullptr);
-    HIP_TRY(call.status);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<float4> rows(2 * n);
     if (n > 0)

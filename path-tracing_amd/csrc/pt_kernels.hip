@@ -322,8 +322,7 @@ int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_
         return fail(PT_ERR_INVALID_ARGUMENT, "tile rectangle outside the image");
     if (s0 < 0 || s1 > p->sqrt_spp * p->sqrt_spp || s0 > s1)
         return fail(PT_ERR_INVALID_ARGUMENT, "sample range outside [0, sqrt_spp^2]");
-    if (scene->dev.n_nodes == 0)
-        return fail(PT_ERR_INVALID_ARGUMENT, "scene has no acceleration structure yet (pt_scene_build_bvh_device or pt_scene_update_bvh)");
+    // (whether the scene has a tree is looked at under the scene's lock, by the caller: requireTree)
     // (the path records keep the segment number in 12 bits and the number of random draws, at most eight per
     // segment, in 16; the reference stops at 128 segments)
     if (p->max_path_segments > 4095)
@@ -342,6 +341,15 @@ int checkRender(const pt_scene* scene, const pt_camera* camera, const pt_render_
     a.pp.maxSegments = p->max_path_segments > 0 ? p->max_path_segments : 128;
     a.pp.rrStart = p->rr_start_segment == 0 ? 5 : (p->rr_start_segment < 0 ? 0 : p->rr_start_segment);
     a.pp.traceNullShadowRays = std::getenv("PT_TRACE_NULL_SHADOW_RAYS") != nullptr;
+    return PT_OK;
+}
+
+// With the scene's lock held (SceneCall): a tree that another thread is rebuilding right now is waited for by taking
+// the lock, not reported as missing.
+int requireTree(const pt_scene* scene)
+{
+    if (scene->dev.n_nodes == 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "scene has no acceleration structure yet (pt_scene_build_bvh_device or pt_scene_update_bvh)");
     return PT_OK;
 }
 
@@ -397,6 +405,7 @@ void pt_scene_destroy(pt_scene* scene)
     if (scene->pending)
         (void)hipEventSynchronize(scene->evDone);
     ptWavefrontRelease(scene);
+    ptMultiRelease(scene);
     for (void* p : scene->owned)
         (void)hipFree(p);
     if (scene->buildArea)
@@ -703,6 +712,8 @@ int pt_render_device(pt_scene* scene, const pt_camera* camera, const pt_render_p
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     SceneCall call(scene, stream);
     HIP_TRY(call.status);
+    if ((rc = requireTree(scene)) != PT_OK)
+        return rc;
     rc = launchRender(scene, a, d_out_rgb, stream, nullptr);
     HIP_TRY(call.done(stream));
     return rc;
@@ -718,6 +729,8 @@ int pt_render_device_noalloc(pt_scene* scene, const pt_camera* camera, const pt_
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     SceneCall call(scene, stream);
     HIP_TRY(call.status);
+    if ((rc = requireTree(scene)) != PT_OK)
+        return rc;
     rc = ptWavefrontRenderStatic(scene, a, d_out_rgb, stream);
     HIP_TRY(call.done(stream));
     return rc;
@@ -732,6 +745,8 @@ static int renderToHost(pt_scene* scene, const pt_camera* camera, const pt_rende
         return rc;
     SceneCall call(scene, nullptr);
     HIP_TRY(call.status);
+    if ((rc = requireTree(scene)) != PT_OK)
+        return rc;
     const size_t bytes = size_t(3) * a.p.width * a.p.height * sizeof(float);
     float* d_out = nullptr;
     unsigned long long* d_cnt = nullptr;
@@ -968,6 +983,8 @@ int pt_render_samples(pt_scene* scene, const pt_camera* camera, const pt_render_
         return fail(PT_ERR_LIMIT, "too many samples for one per-sample call");
     SceneCall call(scene, nullptr);
     HIP_TRY(call.status);
+    if ((rc = requireTree(scene)) != PT_OK)
+        return rc;
     if (!useMegakernel())
         return ptWavefrontSamples(scene, a, out_rgb_per_sample);
     float* d_out = nullptr;
@@ -997,6 +1014,8 @@ int pt_primary_hits(pt_scene* scene, const pt_camera* camera, const pt_render_pa
         return fail(PT_ERR_LIMIT, "too many samples for one call");
     SceneCall call(scene, nullptr);
     HIP_TRY(call.status);
+    if ((rc = requireTree(scene)) != PT_OK)
+        return rc;
     pt_hit* d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(pt_hit)));
     hipLaunchKernelGGL(primaryHitsKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, scene->dev, a, n, d_out);
@@ -1020,10 +1039,13 @@ int pt_trace_rays(pt_scene* scene, uint64_t n, const float* origins, const float
         return PT_OK;
     if (n > (uint64_t(1) << 31))
         return fail(PT_ERR_LIMIT, "too many rays for one call");
-    if (scene->dev.n_nodes == 0)
-        return fail(PT_ERR_INVALID_ARGUMENT, "scene has no acceleration structure yet");
     SceneCall call(scene, nullptr);
     HIP_TRY(call.status);
+    {
+        const int rcTree = requireTree(scene);
+        if (rcTree != PT_OK)
+            return rcTree;
+    }
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     pt_hit* d_out = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 3 * sizeof(float));

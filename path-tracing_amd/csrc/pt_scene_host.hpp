@@ -138,8 +138,14 @@ struct KernelTimes {
         }
     }
     void unchain() { chained = false; }
+    // (called once the stream of the launches recorded so far has been waited for; if a span's events have not
+    // completed all the same -- launches of an earlier call on another stream -- everything is kept for the next
+    // collect rather than dropped)
     void collect()
     {
+        for (const Span& sp : spans)
+            if (sp.stop != sp.start && hipEventQuery(events[sp.stop]) == hipErrorNotReady)
+                return;
         for (const Span& sp : spans) {
             float t = 0.0f;
             if (sp.stop != sp.start && hipEventElapsedTime(&t, events[sp.start], events[sp.stop]) == hipSuccess) {
@@ -160,6 +166,28 @@ struct KernelTimes {
         used = 0;
         chained = false;
     }
+};
+
+// What pt_render_multi keeps with a handle between calls.  As a peer: the image it renders into and the event it
+// records behind its last kernel.  As the first handle: the result buffer of the host-output call, per peer a staging
+// buffer, a copy stream and an event, and the figures of the last combine.
+struct MultiPeer {
+    float* staging = nullptr;
+    size_t stagingCapacity = 0; // floats
+    hipStream_t stream = nullptr;
+    hipEvent_t copied = nullptr;
+};
+struct MultiState {
+    std::mutex mu; // one pt_render_multi call at a time with this handle as the first
+    float* image = nullptr;
+    size_t imageCapacity = 0;
+    hipEvent_t rendered = nullptr;
+    float* result = nullptr;
+    size_t resultCapacity = 0;
+    std::vector<MultiPeer> peers;
+    hipEvent_t combineStart = nullptr, combineStop = nullptr;
+    bool timed = false;
+    int lastKernels = 0, lastCopies = 0, lastDirectCopies = 0;
 };
 
 struct pt_scene {
@@ -186,6 +214,7 @@ struct pt_scene {
     std::mutex mu;
     hipEvent_t evDone = nullptr;
     bool pending = false;
+    MultiState multi;
 };
 
 // One call on a scene: takes the scene's lock, selects its GPU, and orders `stream` behind the previous call's work.
@@ -211,6 +240,9 @@ struct SceneCall {
     }
 };
 
+
+// pt_multi.hip
+void ptMultiRelease(pt_scene* scene);
 
 // pt_wavefront.hip
 int ptWavefrontRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);

@@ -2107,7 +2107,10 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(w.hostCounters, w.counters, kCtrWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        sc->kt.collect();
+        // (only this stream has been waited for: spans of an earlier profiled call on another stream stay where they
+        // are while this call records none)
+        if (sc->kt.enabled)
+            sc->kt.collect();
         // finished when the last iteration shaded nothing and every path number had been handed out
         // well before it (so that its generateKernel cannot have started a path)
         uint64_t alive = 0, goingOnAll = 0;
@@ -2303,9 +2306,11 @@ int ptWavefrontTraceRays(pt_scene* scene, uint64_t n, const float* d_origins, co
 // pixels, and the rest as sample buffer.  In host code the name `scratch` is only a handle for
 // hipGetSymbolAddress: the address of the copy on a device is looked up once per device, with
 // that device current, and host code passes that pointer -- never the name -- to kernels and
-// memsets.  All calls on one GPU share the GPU's copy (they are serialised by `inUse`; a call
-// that finds the area taken fails rather than waits), and the area keeps the last call's
-// contents: runBatch clears what has to start at zero.
+// memsets.  All calls on one GPU share the GPU's copy: a call that arrives while another
+// thread is inside a call on that GPU fails rather than waits (`inUse`), and calls one after
+// the other -- whatever their scenes and streams -- are ordered on the device by an event that
+// each call records behind its last kernel and the next one makes its stream wait for.  The
+// area keeps the last call's contents: runBatch clears what has to start at zero.
 constexpr uint32_t kStaticSlots = 2u * kClassifyRecords * kShards; // 131 072 records per pool
 constexpr uint64_t kStaticMaxPixels = 512u * 1024u;
 constexpr size_t kStaticBytes = size_t(64) << 20;
@@ -2314,8 +2319,10 @@ static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 constexpr int kMaxDevices = 64;
 struct StaticArea {
     unsigned char* ptr = nullptr; // this device's copy of `scratch`
-    bool inUse = false;
-    uint32_t hostCounters[kCtrWords]; // where the counters are read back to (ordinary host memory)
+    bool inUse = false;           // a thread is inside a call that uses the area
+    hipEvent_t done = nullptr;    // behind the last kernel of the last call (made at set-up, with the device current)
+    bool pending = false;
+    uint32_t* hostCounters = nullptr; // where the counters are read back to: pinned host memory, made at set-up
 };
 StaticArea g_static[kMaxDevices];
 std::mutex g_staticMutex;
@@ -2331,7 +2338,12 @@ int ptWavefrontStaticSetup(int device)
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p || (reinterpret_cast<uintptr_t>(p) & 255u) != 0)
         return fail(PT_ERR_DEVICE, "work area of the library image has no usable address on this GPU");
-    g_static[device].ptr = static_cast<unsigned char*>(p);
+    StaticArea& area = g_static[device];
+    if (!area.done)
+        HIP_TRY(hipEventCreateWithFlags(&area.done, hipEventDisableTiming));
+    if (!area.hostCounters)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&area.hostCounters), kCtrWords * sizeof(uint32_t)));
+    area.ptr = static_cast<unsigned char*>(p);
     return PT_OK;
 }
 
@@ -2349,8 +2361,17 @@ int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, 
     {
         std::lock_guard<std::mutex> lock(g_staticMutex);
         if (area.inUse)
-            return fail(PT_ERR_INVALID_ARGUMENT, "the fixed work area of this GPU is in use by another call");
+            return fail(PT_ERR_INVALID_ARGUMENT, "another thread is inside a call that uses the fixed work area of this GPU");
         area.inUse = true;
+    }
+    // behind whatever the previous call on this GPU left running in the area, on any stream
+    if (area.pending) {
+        const hipError_t e = hipStreamWaitEvent(stream, area.done, 0);
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> lock(g_staticMutex);
+            area.inUse = false;
+            return fail(PT_ERR_DEVICE, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+        }
     }
     // the parts of the area
     auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -2377,13 +2398,15 @@ int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, 
     scene->kt.enabled = false;
     rc = renderBatches(scene, w, a, d_out, stream, false);
     scene->kt.enabled = timing;
-    // the area is free for the next call once this call's kernels have run: later calls are ordered behind them by
-    // the scene's event when they use this scene; calls through another scene of this GPU have to be ordered by the
-    // caller (same stream, or an event of its own)
+    // the next call on this GPU waits for this one's kernels on the device
+    const hipError_t recorded = hipEventRecord(area.done, stream);
     {
         std::lock_guard<std::mutex> lock(g_staticMutex);
+        area.pending = area.pending || recorded == hipSuccess;
         area.inUse = false;
     }
+    if (rc == PT_OK && recorded != hipSuccess)
+        return fail(PT_ERR_DEVICE, std::string("hipEventRecord: ") + hipGetErrorString(recorded));
     return rc;
 }
 

@@ -365,11 +365,35 @@ def test_render_multi_with_two_handles_on_one_gpu(cornell, oracle):
             acc = acc + part
         assert same_bits(got, acc / np.float32(9.0))
         np.testing.assert_allclose(got, dev.render(cam, small), rtol=2e-6, atol=1e-7)
+        # (the combine of three handles: one copy and one kernel per peer, nothing for the first handle's own sums)
+        ms, kernels, copies, direct = pt.multi_last_combine(dev)
+        assert kernels <= 3 and copies == 2 and direct == 2 and ms >= 0.0
         out = np.full((64, 96, 3), 5.0, np.float32)
         r = pt.make_params(96, 64, 3, seed=6, tile=(8, 8, 90, 60), samples=(1, 8))
         pt.render_multi([dev, dev2], cam, r, pt.abi.PT_SHARD_SAMPLES, out=out)
         assert np.all(out[:8] == 5.0) and np.all(out[:, 90:] == 5.0)
         np.testing.assert_allclose(out[8:60, 8:90], dev.render(cam, r)[8:60, 8:90], rtol=2e-6, atol=1e-7)
+        # the device-output form: result in a buffer of the first handle's GPU, on a stream of the caller's; twice,
+        # the second time into the buffers the first call left with the handles
+        from hiprt import Hip
+        hip = Hip()
+        stream = hip.stream()
+        d_out = hip.zeros(300 * 600 * 12)
+        try:
+            for mode, want_img in ((pt.abi.PT_SHARD_TILES, single), (pt.abi.PT_SHARD_SAMPLES, None), (pt.abi.PT_SHARD_TILES, single)):
+                pt.render_multi_device([dev, dev2, dev3], cam, p, d_out.value, mode, stream.value)
+                hip.sync()
+                got = hip.to_host(d_out, (300, 600, 3))
+                if want_img is not None:
+                    assert same_bits(got, want_img)
+                else:
+                    np.testing.assert_allclose(got, single, rtol=2e-6, atol=1e-7)
+            ms, kernels, copies, direct = pt.multi_last_combine(dev)
+            assert kernels == 2 and copies == 2
+            print("combine of three handles at 600x300: %.3f ms" % ms)
+        finally:
+            hip.free(d_out)
+            hip.destroy_stream(stream)
 
 
 def test_full_size_properties(oracle, golden_dir):

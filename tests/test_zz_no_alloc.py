@@ -84,3 +84,33 @@ def test_noalloc_render_of_a_scene_in_memory_and_a_second_scene():
         want, got, before, after = render_both(hip, dev2, cam2, q)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert before == after
+
+
+def test_noalloc_calls_of_two_scenes_on_two_streams_are_ordered_by_the_library(golden_dir):
+    """Two scenes of one GPU, each on its own stream, no synchronisation between the calls: the second call's
+    kernels wait on the device for the first call's (the area's event), so both images are the allocating
+    renderer's, bit for bit -- several rounds, so that a call regularly finds the other's kernels still running."""
+    hip = Hip()
+    scene = pt.LoadedScene(os.path.join(golden_dir, "cornell_glossy.ptscene"))
+    cam = pt.load_camera(os.path.join(golden_dir, "cornell_wide.ptcam"))
+    s2, cam2, _ = scenes.build("materials")
+    sa, sb = hip.stream(), hip.stream()
+    pa, pb = pt.make_params(256, 192, 3, seed=21), pt.make_params(160, 120, 2, seed=22)
+    with pt.DeviceScene(scene) as dev, pt.DeviceScene(s2) as dev2:
+        wa, wb = hip.zeros(pa.width * pa.height * 12), hip.zeros(pb.width * pb.height * 12)
+        dev.render_device(cam, pa, wa.value, None)
+        dev2.render_device(cam2, pb, wb.value, None)
+        hip.sync()
+        want_a, want_b = hip.to_host(wa, (pa.height, pa.width, 3)), hip.to_host(wb, (pb.height, pb.width, 3))
+        ga, gb = hip.zeros(pa.width * pa.height * 12), hip.zeros(pb.width * pb.height * 12)
+        for _ in range(4):
+            dev.render_device_noalloc(cam, pa, ga.value, sa.value)
+            dev2.render_device_noalloc(cam2, pb, gb.value, sb.value)
+        hip.sync()
+        got_a, got_b = hip.to_host(ga, (pa.height, pa.width, 3)), hip.to_host(gb, (pb.height, pb.width, 3))
+        assert np.array_equal(got_a.view(np.uint32), want_a.view(np.uint32))
+        assert np.array_equal(got_b.view(np.uint32), want_b.view(np.uint32))
+        for b in (wa, wb, ga, gb):
+            hip.free(b)
+    hip.destroy_stream(sa)
+    hip.destroy_stream(sb)
