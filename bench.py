@@ -11,15 +11,18 @@ frames with the frames left over split by samples (frames); the float buffers ar
 sum-reduce inside the timed region.  Rank 0 prints one JSON line.
 
 The line also carries
-  roofline      for the kernel with the most device time: what it achieves against the limit that binds it.
-                A tracing kernel of a scene whose tables fit LDS: FP32 vector flops of the walk (30 per box test, 60
-                per surface test, counted by the instrumented kernel) over the kernel's duration against the FP32
-                vector peak.  A tracing kernel of a scene in memory: bytes the executed walk has to move (32 per box
-                row, 48 per surface test, the ray records in and out; counted by the instrumented kernel) over the
-                duration against the HBM peak.  The shading kernel (which has overtaken the tracing kernel on the
-                small scenes): the bytes of path state it gathers and scatters per shaded vertex against the HBM
-                peak.  Each beside the HBM bytes rocprofv3's counters saw for the same launch (profiles/).
+  roofline      for the kernel with the most device time, against the limit that binds the workload.  Scenes whose
+                tables fit LDS (cornell, frames): the reference algorithm needs no memory traffic beyond the pixel
+                contribution there, so the limit is FP32 vector issue -- useful flops of the kernel's share of the
+                algorithm (30 per box test, 60 per surface test, counted by the instrumented kernel; 300 per shaded
+                vertex, 60 per light test) over its duration against the FP32 vector peak.  Scenes in memory
+                (mesh, textured): bytes the executed walk has to move (32 per box row, 48 per surface test, the ray
+                records in and out; counted by the instrumented kernel) over the duration against the HBM peak.  Each
+                beside the HBM bytes rocprofv3's counters saw for the same launches (profiles/traffic_*.json).
   roofline_trace  the same for the tracing kernel when another kernel has the most time.
+  state_traffic (LDS scenes) what the wavefront design moves through HBM per path sample -- path records, hit lists,
+                shadow-ray queues -- by its own byte model and as measured, against the 12 bytes per sample that the
+                algorithm itself needs, and the dominant kernel priced against the HBM peak by that traffic.
   rmse          the rendered image, averaged over 20x20 pixel blocks, against a converged 96x54 image of the same
                 view rendered by the reference with its own generator (tests/golden/converged_*.npz).
   cpu_baseline  the compiled reference (oracle/_ref/libpt_ref_fast.so: the reference's own pathSample / BVH /
@@ -67,7 +70,10 @@ def cpu_baseline(scene, cam, width, height, seed, t0=0.0, t1=0.0):
     lib = refbind.REF_FAST_LIB if os.path.exists(refbind.REF_FAST_LIB) else refbind.REF_LIB
     if not os.path.exists(lib):
         return None
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # The cores this job may use: a one-GPU job on the box is granted a share of the host (OMP_NUM_THREADS is set to
+    # it, 16 there, and wider pools are killed), not the os.cpu_count() CPUs of the whole machine; both are stated.
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(allowed, 16)
     R = refbind.Reference(lib)
     d = scene.desc()
     devnull = os.open(os.devnull, os.O_WRONLY)
@@ -88,6 +94,8 @@ def cpu_baseline(scene, cam, width, height, seed, t0=0.0, t1=0.0):
         os.close(saved)
     n = width * height * sqrt_spp * sqrt_spp
     return {"value": n / runs[1], "unit": "path samples/s", "cores": threads, "kind": "reference",
+            "host_cpus_visible": os.cpu_count(), "host_cpus_allowed": allowed,
+            "cores_note": "threads = OMP_NUM_THREADS as set for this job (its share of the host), else min(allowed CPUs, 16)",
             "runs_s": runs,
             "sample": "%dx%d at %d spp (%d path samples), median of 3 runs (%.1f s), reference's own generator, "
                       "g++ -Ofast -march=x86-64-v3 -fopenmp" % (width, height, sqrt_spp * sqrt_spp, n, runs[1])}
@@ -132,9 +140,14 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sqrt-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bvh", choices=["host", "device"], default="device",
+    ap.add_argument("--pmc-pass", action="store_true",
+                    help="for a rocprofv3 --pmc run: exactly the launches of the timed steps (no warm-up is needed, no "
+                         "instrumented renders, no CPU baseline), so that per-kernel counter averages are over the very "
+                         "launches whose durations the normal run reports")
+    ap.add_argument("--bvh", choices=["file", "device"], default="device",
                     help="device: the tree built by pt_scene_build_bvh_device (surface-area builder, the faster tree on every "
-                         "workload); host: the reference's tree (pt_bvh_build)")
+                         "workload); file: the tree the reference built, as stored in the workload's scene file (cornell, "
+                         "textured: the mesh is generated and the animation rebuilds its tree per frame, so neither has one)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,6 +196,8 @@ def main():
     frames = extra.get("frames")
     mode = extra.get("sharding", "samples")
     max_seg = extra.get("max_path_segments", 0)
+    if args.bvh == "file" and (frames or scene.desc().n_bvh_nodes == 0):
+        raise SystemExit("--bvh file: this workload's scene has no stored tree for its frames (use --bvh device)")
     dev = pt.DeviceScene(scene, device=local_rank)
     bvh_build_ms = None
     if args.bvh == "device":
@@ -214,18 +229,7 @@ def main():
             dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
 
     def frame_tree(t0f, t1f):
-        if args.bvh == "device":
-            dev.build_bvh_device(t0f, t1f, stream.cuda_stream)
-        else:
-            dev.update_bvh(scene.build_bvh(t0f, t1f) if hasattr(scene, "build_bvh") else host_tree(t0f, t1f))
-
-    flat_for_trees = []
-
-    def host_tree(t0f, t1f):
-        # (a scene file is read-only: the reference's builder runs on a copy of its tables)
-        if not flat_for_trees:
-            flat_for_trees.append(pt.FlatScene.from_desc(scene.desc()))
-        return flat_for_trees[0].build_bvh(t0f, t1f)
+        dev.build_bvh_device(t0f, t1f, stream.cuda_stream)
 
     def step(timed=False):
         if timed:
@@ -297,6 +301,18 @@ def main():
         elapsed = float(t.item())
 
     result = None
+    if args.pmc_pass:
+        if rank == 0:
+            print(json.dumps({"pmc_pass": True, "workload": args.workload, "steps": args.steps, "ms_per_step": elapsed / args.steps * 1e3,
+                              "kernels": {k: v[0] / args.steps for k, v in kernel_times.items() if v[0]}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
+        watchdog_file.close()
+        if os.path.getsize(watchdog_path) == 0:
+            os.remove(watchdog_path)
+        return
     if rank == 0:
         n_renders = len(frames) if frames else 1
         total_samples = float(W) * H * spp * n_renders * args.steps
@@ -342,14 +358,17 @@ def main():
                          + 57 * walk_per_sample["retry_rays"],
                 "flops": 30 * walk_per_sample["retry_node_visits"] + 60 * walk_per_sample["retry_surface_tests"]},
             "shadeHitsKernel": {
-                # per shaded vertex: its place in the hit list (4 bytes), the path record in (88) and out (72), the surface's
-                # attributes and plane normal or vertices (32 to 64: 48 taken), a shadow-queue entry (48); 12 bytes per
-                # finished sample.  (The rows of the lights are the same for every lane: scalar loads that stay in cache.)
-                "bytes": ref_per_sample["vertices"] * (4 + 88 + 72 + 48 + 48) + 12,
+                # path state the kernel gathers and scatters per shaded vertex: its place in the hit list (4 bytes), the
+                # record in (four 16-byte rows and the 8-byte key: 72) and, for a path that goes on, out (56), the
+                # surface's attributes and plane normal or vertices (32 to 64: 48 taken), a shadow-queue entry (48).
+                # (The rows of the lights are the same for every lane: scalar loads that stay in cache.)
+                "bytes": ref_per_sample["vertices"] * (4 + 72 + 56 + 48 + 48),
                 "flops": 300 * ref_per_sample["vertices"] + 60 * ref_per_sample["light_tests"]},
         }
+        n_surf = scene.desc().n_surfaces
+        table_bytes = (2 * (2 * n_surf - 1) + 3 * n_surf) * 16
         in_lds = kernel_times.get("traceKernel", (0, 0))[0] > 0 and kernel_times.get("traceOrderedKernel", (0, 0))[0] == 0 \
-            and (2 * scene.desc().n_bvh_nodes + 3 * scene.desc().n_surfaces) * 16 <= 16384
+            and table_bytes <= 16384
         if in_lds:
             # node and surface rows are read from the copy in LDS: only the ray records cross the memory system
             per_sample["traceKernel"]["lds_bytes"] = 32 * walk_per_sample["box_rows"] + 48 * walk_per_sample["surface_tests"]
@@ -366,72 +385,75 @@ def main():
                 k["samples_per_launch"] = samples_per_launch
                 k["algorithmic_GBps"] = per_sample[name]["bytes"] * samples_per_launch / secs / 1e9
                 k["algorithmic_TFLOPs"] = per_sample[name]["flops"] * samples_per_launch / secs / 1e12
-                traffic = measured_traffic(args.workload, name)[0] if args.bvh == "device" else None
-                k["hbm_bytes_per_launch"] = traffic
-                if traffic:
-                    k["hbm_GBps"] = traffic / secs / 1e9
+            traffic = measured_traffic(args.workload, name)[0] if args.bvh == "device" else None
+            k["hbm_bytes_per_launch"] = traffic
+            if traffic:
+                k["hbm_GBps"] = traffic / (total_ms / launches * 1e-3) / 1e9
             kernels[name] = k
         dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
-        dk = kernels[dominant]
-        traffic, traffic_note = measured_traffic(args.workload, dominant)
+        traffic_note = measured_traffic(args.workload, dominant)[1]
         if args.bvh != "device":
-            traffic, traffic_note = None, "the committed PMC passes were taken with the device-built tree"
-        alg_bytes_launch = per_sample.get(dominant, {"bytes": 0})["bytes"] * dk.get("samples_per_launch", 0)
-        common = {"kernel": dominant, "kernel_avg_us": dk["avg_us"], "kernel_launches_per_step": dk["launches_per_step"],
-                  "samples_per_launch": dk.get("samples_per_launch"), "traffic": traffic, "traffic_note": traffic_note,
-                  "algorithmic_bytes_per_launch": alg_bytes_launch,
-                  "traffic_over_algorithmic": (traffic / alg_bytes_launch) if traffic and alg_bytes_launch else None}
-        if dominant == "shadeHitsKernel":
-            # the shading kernel gathers path records through the hit list and scatters the paths that go on: what it
-            # is priced against is the memory system
-            ach = dk.get("algorithmic_GBps", 0.0)
-            roofline = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                            traffic_GBps=dk.get("hbm_GBps"),
-                            traffic_frac=(dk["hbm_GBps"] / HBM_PEAK_GBS) if dk.get("hbm_GBps") else None,
-                            bytes_per_sample=per_sample[dominant]["bytes"],
-                            note="the shading kernel has the most device time by a small margin over the tracing kernel "
-                                 "(`roofline_trace`); achieved = bytes it has to move per shaded vertex (hit-list entry, path "
-                                 "record in and out, surface attributes, shadow-queue entry) / duration; it waits for those "
-                                 "gathers 64 % of its wave-cycles (profiles/r02_pmc_sq_cornell.txt)")
-        elif in_lds:
-            # node and surface tables are in LDS: the walk never touches HBM, what binds is vector issue
-            ach = dk.get("algorithmic_TFLOPs", 0.0)
-            roofline = dict(common, bound="fp32-valu", achieved=ach, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=ach / VALU_PEAK_TFLOPS, peak_unfused=VALU_PEAK_UNFUSED_TFLOPS,
-                            frac_unfused=ach / VALU_PEAK_UNFUSED_TFLOPS,
-                            flops_per_sample=per_sample.get(dominant, {}).get("flops"),
-                            hbm_frac=(dk["hbm_GBps"] / HBM_PEAK_GBS) if dk.get("hbm_GBps") else None,
-                            note="scene tables (%d bytes) are held in LDS; flops = 30 per box test + 60 per surface test of "
-                                 "the executed walk (instrumented kernel), no fused multiply-add (contraction is off for "
-                                 "bit-reproducible results), so 78.6 TFLOP/s is the issue limit of this code; `traffic` is "
-                                 "path-state traffic" % ((2 * scene.desc().n_bvh_nodes + 3 * scene.desc().n_surfaces) * 16))
+            traffic_note = "the committed PMC passes were taken with the device-built tree"
+
+        def valu_line(name):
+            """A kernel against the FP32 vector peak: useful flops of the reference algorithm's work (30 per box test,
+            60 per surface test of the executed walk; 300 per shaded vertex, 60 per light test) over its duration."""
+            k = kernels[name]
+            ach = k.get("algorithmic_TFLOPs", 0.0)
+            return {"kernel": name, "kernel_avg_us": k["avg_us"], "kernel_launches_per_step": k["launches_per_step"],
+                    "samples_per_launch": k.get("samples_per_launch"), "bound": "fp32-valu", "achieved": ach,
+                    "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS,
+                    "peak_unfused": VALU_PEAK_UNFUSED_TFLOPS, "frac_unfused": ach / VALU_PEAK_UNFUSED_TFLOPS,
+                    "flops_per_sample": per_sample.get(name, {}).get("flops"),
+                    "traffic": k.get("hbm_bytes_per_launch"), "traffic_note": traffic_note}
+
+        def hbm_line(name, what):
+            k = kernels[name]
+            ach = k.get("algorithmic_GBps", 0.0)
+            alg = per_sample.get(name, {"bytes": 0})["bytes"] * k.get("samples_per_launch", 0)
+            t = k.get("hbm_bytes_per_launch")
+            return {"kernel": name, "kernel_avg_us": k["avg_us"], "kernel_launches_per_step": k["launches_per_step"],
+                    "samples_per_launch": k.get("samples_per_launch"), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_per_sample": per_sample.get(name, {}).get("bytes"),
+                    "algorithmic_bytes_per_launch": alg, "traffic": t, "traffic_note": traffic_note,
+                    "traffic_GBps": k.get("hbm_GBps"), "traffic_frac": (k["hbm_GBps"] / HBM_PEAK_GBS) if k.get("hbm_GBps") else None,
+                    "traffic_over_algorithmic": (t / alg) if t and alg else None, "note": what}
+
+        state_traffic = None
+        if in_lds:
+            # The scene's tables (%d bytes) are in LDS: the reference algorithm needs no memory traffic per sample beyond
+            # the pixel contribution, and what binds is vector issue.  The headline is therefore the dominant kernel
+            # against the FP32 vector peak; what the kernels do move -- the path state of the wavefront design -- is
+            # reported under its own name.
+            roofline = valu_line(dominant)
+            roofline["note"] = ("scene tables (%d bytes) are held in LDS; useful flops of the reference algorithm's work over the "
+                                "kernel's duration; contraction is off for bit-reproducible results, so 78.6 TFLOP/s is the "
+                                "issue limit of this code (frac_unfused); `traffic` is path-state traffic, see state_traffic"
+                                % table_bytes)
+            pmc_step = sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values() if k.get("hbm_bytes_per_launch"))
+            model_step = sum(per_sample[n]["bytes"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
+                             for n in kernels if n in per_sample)
+            state_traffic = {
+                "what": "path records, hit lists and shadow-ray queues of the wavefront design that cross HBM per path sample, "
+                        "all kernels of a step; the reference algorithm on an LDS-resident scene needs 12 bytes per sample",
+                "algorithmic_hbm_bytes_per_sample": 12,
+                "model_bytes_per_sample": model_step / rank_samples,
+                "measured_bytes_per_sample": (pmc_step / rank_samples) if pmc_step else None,
+                "measured_over_algorithmic": (pmc_step / rank_samples / 12.0) if pmc_step else None,
+                "measured_GBps": (pmc_step / (last_ms * 1e-3) / 1e9) if pmc_step else None,
+                "measured_frac_of_hbm_peak": (pmc_step / (last_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc_step else None,
+                "dominant_kernel": hbm_line(dominant, "path state the kernel has to move by the design's own byte model / duration"),
+            }
         else:
-            ach = dk.get("algorithmic_GBps", 0.0)
-            roofline = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                            traffic_GBps=dk.get("hbm_GBps"),
-                            traffic_frac=(dk["hbm_GBps"] / HBM_PEAK_GBS) if dk.get("hbm_GBps") else None,
-                            bytes_per_sample=per_sample.get(dominant, {}).get("bytes"),
-                            note="achieved = bytes the executed walk has to move (32 per box row, 48 per surface test, ray "
-                                 "records in and out; counts from the instrumented kernel) / kernel duration; `traffic` = "
-                                 "HBM bytes per launch from rocprofv3 counters (profiles/)")
+            roofline = hbm_line(dominant, "achieved = bytes the executed walk has to move (32 per box row, 48 per surface test, ray "
+                                          "records in and out; counts from the instrumented kernel) / kernel duration; `traffic` = "
+                                          "HBM bytes per launch from rocprofv3 counters (profiles/)")
         # the tracing kernel against its own limit, whichever kernel has the most time
         trace_name = max((n for n in kernels if n in ("traceKernel", "traceOrderedKernel")), key=lambda n: kernels[n]["ms_per_step"],
                          default=None)
         roofline_trace = None
         if trace_name and trace_name != dominant:
-            tk = kernels[trace_name]
-            if in_lds:
-                ach = tk.get("algorithmic_TFLOPs", 0.0)
-                roofline_trace = {"kernel": trace_name, "kernel_avg_us": tk["avg_us"], "bound": "fp32-valu", "achieved": ach,
-                                  "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS,
-                                  "peak_unfused": VALU_PEAK_UNFUSED_TFLOPS, "frac_unfused": ach / VALU_PEAK_UNFUSED_TFLOPS,
-                                  "flops_per_sample": per_sample[trace_name]["flops"],
-                                  "traffic": tk.get("hbm_bytes_per_launch")}
-            else:
-                ach = tk.get("algorithmic_GBps", 0.0)
-                roofline_trace = {"kernel": trace_name, "kernel_avg_us": tk["avg_us"], "bound": "hbm", "achieved": ach,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": tk.get("hbm_bytes_per_launch")}
+            roofline_trace = valu_line(trace_name) if in_lds else hbm_line(trace_name, "as `roofline`, for the tracing kernel")
         # all kernels of one step together against both limits
         total_flops = sum(per_sample[n]["flops"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
                           for n in kernels if n in per_sample)
@@ -463,6 +485,7 @@ def main():
                     if not args.sqrt_spp and not (frames and world > 1) else None,
             "roofline": roofline,
             "roofline_trace": roofline_trace,
+            "state_traffic": state_traffic,
             "whole_step": whole,
             "kernels": kernels,
             "work_per_sample": ref_per_sample,

@@ -502,15 +502,6 @@ int pt_mesh_reindex(int device, const int32_t* corner_vi, const int32_t* corner_
 
 /* ------------------------------------------------------- host-side helpers -- */
 
-/* Build the acceleration structure over [t0, t1] exactly as
- * BVHNode::buildBVH + BVHTreeLinear::flattenBVH do (reference
- * src/15/bvh.hpp:36-108,146-176): same surface bounds, same per-node sort
- * along the longest axis, same SAH sweep, same pre-order.  out_nodes must
- * hold 2 * n_surfaces - 1 entries.  Fails with PT_ERR_LIMIT if the tree is
- * deeper than 128 levels (the reference aborts there). */
-int pt_bvh_build(const pt_scene_desc* desc, float t0, float t1, pt_bvh_node* out_nodes,
-                 uint32_t* out_depth);
-
 /* Per-vertex tangents of one mesh as Mesh's constructor computes them
  * (reference src/15/mesh.hpp:10-55). */
 int pt_mesh_compute_tangents(const float* positions, const float* normals, const float* texcoords,

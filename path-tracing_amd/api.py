@@ -85,8 +85,6 @@ def lib():
                                       C.POINTER(abi.pt_hit)]
         L.pt_trace_rays.argtypes = [C.c_void_p, C.c_uint64, _fp, _fp, _fp, C.c_float, C.c_float,
                                     C.POINTER(abi.pt_hit)]
-        L.pt_bvh_build.argtypes = [C.POINTER(abi.pt_scene_desc), C.c_float, C.c_float, C.POINTER(abi.pt_bvh_node),
-                                   _u32p]
         L.pt_mesh_compute_tangents.argtypes = [_fp, _fp, _fp, C.c_uint32, _u32p, C.c_uint32, _fp]
         L.pt_scene_desc_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(abi.pt_scene_desc))]
         L.pt_scene_desc_save.argtypes = [C.POINTER(abi.pt_scene_desc), C.c_char_p]
@@ -215,6 +213,15 @@ def n_samples(p):
 
 
 # ------------------------------------------------------------ flat scenes --
+
+_host_tree_builder = None
+
+
+def set_host_tree_builder(fn):
+    """fn(desc, t0, t1, nodes) fills the NODE_DTYPE array `nodes` (2 * surfaces - 1 entries) and returns the depth."""
+    global _host_tree_builder
+    _host_tree_builder = fn
+
 
 class FlatScene:
     """A flat scene in host memory: numpy arrays behind one pt_scene_desc.
@@ -490,15 +497,19 @@ class FlatScene:
         return d
 
     def build_bvh(self, t0=0.0, t1=0.0):
-        """Scene::buildBVH(t0, t1) (reference src/15/scene.hpp:69-72) via pt_bvh_build."""
+        """A host-built tree for this scene, Scene::buildBVH(t0, t1) (reference src/15/scene.hpp:69-72), through the
+        builder registered with set_host_tree_builder.  The library itself builds trees on the device
+        (DeviceScene.build_bvh_device) or takes them from the caller; the tests register the reference's builder
+        as restated by their checker, so that scenes they put together get the reference's topology."""
+        if _host_tree_builder is None:
+            raise PtError(-2, "no host-side tree builder registered: build the tree on the device "
+                          "(DeviceScene.build_bvh_device) or hand over the reference's nodes")
         self.nodes = np.zeros(0, NODE_DTYPE)
         d = self.desc()
+        _check(lib().pt_scene_desc_validate(C.byref(d)))
         nodes = np.zeros(2 * len(self.surfaces) - 1, NODE_DTYPE)
-        depth = C.c_uint32()
-        _check(lib().pt_bvh_build(C.byref(d), t0, t1, nodes.ctypes.data_as(C.POINTER(abi.pt_bvh_node)),
-                                  C.byref(depth)))
+        self.depth = int(_host_tree_builder(d, t0, t1, nodes))
         self.nodes = nodes
-        self.depth = int(depth.value)
         return nodes
 
     def save(self, path):

@@ -1,11 +1,6 @@
 // pt_host.cpp -- host-side helpers of libptamd.so that need no GPU:
-// the acceleration-structure builder, mesh tangents, scene files, validation.
-//
-// pt_bvh_build reproduces BVHNode::buildBVH + BVHTreeLinear::flattenBVH
-// (reference src/15/bvh.hpp:36-108,146-176) so that the node array -- boxes,
-// topology and order -- is the one the reference would build for the same
-// surfaces: the traversal order, and with it which of two equally distant
-// surfaces a ray reports, depends on it.
+// mesh tangents, scene files, validation.  (Trees are built on the device,
+// pt_scene_build_bvh_device, or handed over by the caller as the reference built them.)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -21,171 +16,6 @@
 using namespace ptv;
 
 namespace {
-
-// The reference evaluates animations with the C library when it computes
-// surface bounds on the host; so does this builder.
-struct LibmMath {
-    static float sin(float x) { return std::sin(x); }
-    static float cos(float x) { return std::cos(x); }
-    static float acos(float x) { return std::acos(x); }
-};
-
-struct Box {
-    V3 lo, hi;
-};
-
-inline Box boxOf(V3 A, V3 B, V3 C) // surface_triangle.hpp:11-21
-{
-    return Box{ v3(std::min(A.x, std::min(B.x, C.x)), std::min(A.y, std::min(B.y, C.y)), std::min(A.z, std::min(B.z, C.z))),
-                v3(std::max(A.x, std::max(B.x, C.x)), std::max(A.y, std::max(B.y, C.y)), std::max(A.z, std::max(B.z, C.z))) };
-}
-
-inline Box merge(const Box& a, const Box& b) // aabb.hpp:63-71
-{
-    return Box{ v3(std::min(a.lo.x, b.lo.x), std::min(a.lo.y, b.lo.y), std::min(a.lo.z, b.lo.z)),
-                v3(std::max(a.hi.x, b.hi.x), std::max(a.hi.y, b.hi.y), std::max(a.hi.z, b.hi.z)) };
-}
-
-inline float comp(V3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
-
-inline int longestAxis(const Box& b) // aabb.hpp:23-33
-{
-    int axis = 2;
-    V3 l = b.hi - b.lo;
-    if (l.x > l.y && l.x > l.z)
-        axis = 0;
-    else if (l.y > l.z)
-        axis = 1;
-    return axis;
-}
-
-inline float surfaceArea(const Box& b) // aabb.hpp:35-39
-{
-    V3 l = b.hi - b.lo;
-    return 2.0f * (l.x * l.y + l.y * l.z + l.x * l.z);
-}
-
-// Surface::aabb(t0, t1): surface_triangle.hpp:32-63, surface_sphere.hpp:50-69
-Box surfaceBox(const pt_scene_desc& d, const pt_surface& s, float t0, float t1)
-{
-    const int steps = 16;
-    if (s.type == PT_SURF_TRIANGLE) {
-        const pt_mesh& m = d.meshes[s.owner];
-        const uint32_t* idx = d.indices + m.first_index + 3 * size_t(s.index);
-        V3 A = v3(d.positions + 3 * size_t(m.first_vertex + idx[0]));
-        V3 B = v3(d.positions + 3 * size_t(m.first_vertex + idx[1]));
-        V3 C = v3(d.positions + 3 * size_t(m.first_vertex + idx[2]));
-        if (m.animation < 0)
-            return boxOf(A, B, C);
-        const pt_animation& an = d.animations[m.animation];
-        Xform T0 = animationAt<LibmMath>(an, t0);
-        Box box = boxOf(apply(T0, A), apply(T0, B), apply(T0, C));
-        for (int i = 1; i < steps; i++) {
-            float t = mixf(t0, t1, i / (steps - 1.0f));
-            Xform T = animationAt<LibmMath>(an, t);
-            box = merge(box, boxOf(apply(T, A), apply(T, B), apply(T, C)));
-        }
-        return box;
-    }
-    const pt_sphere& q = d.spheres[s.owner];
-    V3 center = v3(q.center);
-    if (q.animation < 0)
-        return Box{ center - v3(q.radius), center + v3(q.radius) };
-    const pt_animation& an = d.animations[q.animation];
-    Xform T0 = animationAt<LibmMath>(an, t0);
-    V3 c0 = apply(T0, center);
-    float r0 = T0.scaling.x * q.radius;
-    Box box{ c0 - v3(r0), c0 + v3(r0) };
-    for (int i = 1; i < steps; i++) {
-        float t = mixf(t0, t1, i / (steps - 1.0f));
-        Xform T = animationAt<LibmMath>(an, t);
-        V3 c = apply(T, center);
-        float r = T.scaling.x * q.radius;
-        box = merge(box, Box{ c - v3(r), c + v3(r) });
-    }
-    return box;
-}
-
-struct Builder {
-    const std::vector<Box>& boxes;
-    std::vector<unsigned int> subset;
-    std::vector<float> areas0, areas1;
-    pt_bvh_node* nodes;
-    size_t nodeCount = 0;
-    size_t maxDepth = 0;
-
-    explicit Builder(const std::vector<Box>& b, pt_bvh_node* out)
-        : boxes(b), subset(b.size()), areas0(b.size()), areas1(b.size()), nodes(out)
-    {
-        for (size_t i = 0; i < b.size(); i++)
-            subset[i] = (unsigned int)i;
-    }
-
-    float sah(size_t off, size_t size, int i) const // bvh.hpp:18-22
-    {
-        return i * areas0[off + i - 1] + (size - i) * areas1[off + i];
-    }
-
-    // bvh.hpp:36-90 (build) fused with :146-159 (pre-order flattening)
-    size_t build(size_t I, size_t N, size_t depth)
-    {
-        size_t my = nodeCount++;
-        maxDepth = std::max(maxDepth, depth);
-        if (N == 1) {
-            const Box& b = boxes[subset[I]];
-            setBox(my, b);
-            nodes[my].link = uint64_t(subset[I]) * 2;
-            return my;
-        }
-        Box box = boxes[subset[I]];
-        for (size_t i = 1; i < N; i++)
-            box = merge(box, boxes[subset[I + i]]);
-        setBox(my, box);
-        const int axis = longestAxis(box);
-        const std::vector<Box>& bx = boxes;
-        std::sort(subset.begin() + I, subset.begin() + I + N, [&bx, axis](unsigned int i, unsigned int j) {
-            // AABBSorter (aabb.hpp:84-87): compare box centres, centre = mix(lo, hi, 0.5)
-            float ci = mixf(comp(bx[i].lo, axis), comp(bx[i].hi, axis), 0.5f);
-            float cj = mixf(comp(bx[j].lo, axis), comp(bx[j].hi, axis), 0.5f);
-            return ci < cj;
-        });
-        Box box0 = boxes[subset[I]];
-        areas0[I + 0] = surfaceArea(box0);
-        for (size_t i = 1; i < N - 1; i++) {
-            box0 = merge(box0, boxes[subset[I + i]]);
-            areas0[I + i] = surfaceArea(box0);
-        }
-        Box box1 = boxes[subset[I + N - 1]];
-        areas1[I + N - 1] = surfaceArea(box1);
-        for (int i = int(N) - 2; i > 0; i--) {
-            box1 = merge(box1, boxes[subset[I + i]]);
-            areas1[I + i] = surfaceArea(box1);
-        }
-        int splitIndex = 1;
-        float minSAH = sah(I, N, 1);
-        for (size_t i = 2; i < N; i++) {
-            float SAH = sah(I, N, int(i));
-            if (SAH < minSAH) {
-                minSAH = SAH;
-                splitIndex = int(i);
-            }
-        }
-        build(I, size_t(splitIndex), depth + 1);
-        size_t child2 = build(I + splitIndex, N - splitIndex, depth + 1);
-        nodes[my].link = uint64_t(child2) * 2 + 1;
-        return my;
-    }
-
-    void setBox(size_t k, const Box& b)
-    {
-        nodes[k].lo[0] = b.lo.x;
-        nodes[k].lo[1] = b.lo.y;
-        nodes[k].lo[2] = b.lo.z;
-        nodes[k].hi[0] = b.hi.x;
-        nodes[k].hi[1] = b.hi.y;
-        nodes[k].hi[2] = b.hi.z;
-    }
-};
 
 struct OwnedDesc {
     pt_scene_desc desc; // first member: its address is the address of the record
@@ -407,32 +237,6 @@ try {
             }
         }
     }
-    return PT_OK;
-} catch (...) {
-    return ptint::caught();
-}
-
-int pt_bvh_build(const pt_scene_desc* d, float t0, float t1, pt_bvh_node* out_nodes, uint32_t* out_depth)
-try {
-    if (!d || !out_nodes)
-        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-    if (d->n_surfaces == 0)
-        return fail(PT_ERR_INVALID_ARGUMENT, "cannot build over zero surfaces");
-    pt_scene_desc tmp = *d; // validate everything but the (absent or stale) nodes
-    tmp.n_bvh_nodes = 0;
-    tmp.bvh_nodes = nullptr;
-    int rc = pt_scene_desc_validate(&tmp);
-    if (rc != PT_OK)
-        return rc;
-    std::vector<Box> boxes(d->n_surfaces);
-    for (uint64_t i = 0; i < d->n_surfaces; i++)
-        boxes[i] = surfaceBox(*d, d->surfaces[i], t0, t1);
-    Builder b(boxes, out_nodes);
-    b.build(0, boxes.size(), 1);
-    if (out_depth)
-        *out_depth = uint32_t(b.maxDepth);
-    if (b.maxDepth > 128)
-        return fail(PT_ERR_LIMIT, "acceleration structure deeper than 128 levels");
     return PT_OK;
 } catch (...) {
     return ptint::caught();

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import refbind
+    refbind.register_host_tree_builder()
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -302,6 +302,13 @@ class Oracle:
                                            C.byref(cnt)))
         return (out, cnt) if counters else out
 
+    def bvh_build(self, desc, t0, t1, nodes):
+        """Scene::buildBVH(t0, t1) of the reference, restated: fills `nodes`, returns the depth."""
+        depth = C.c_uint32()
+        self._check(self.lib.oracle_bvh_build(desc, C.c_float(t0), C.c_float(t1),
+                                              nodes.ctypes.data_as(C.POINTER(abi.pt_bvh_node)), C.byref(depth)))
+        return int(depth.value)
+
     def render_samples(self, desc, cam, params, math_mode=1):
         out = np.empty((_n_samples(params), 3), np.float32)
         self._check(self.lib.oracle_render_samples(desc, C.byref(cam), C.byref(params), math_mode, _f(out)))
@@ -432,3 +439,13 @@ class Oracle:
         self._check(self.lib.oracle_kat_rng(C.c_uint64(seed), C.c_uint64(pixel), C.c_uint64(sample), C.c_uint32(n),
                                             _f(out)))
         return out
+
+
+def register_host_tree_builder():
+    """Scenes that the tests put together get their host-built trees from the checker's restatement of the
+    reference's builder (the product library builds trees on the device only)."""
+    import path_tracing_amd as pt
+    if not os.path.exists(ORACLE_LIB):
+        return
+    oracle = Oracle()
+    pt.set_host_tree_builder(lambda desc, t0, t1, nodes: oracle.bvh_build(C.byref(desc), t0, t1, nodes))

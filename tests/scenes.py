@@ -16,7 +16,15 @@ from path_tracing_amd import abi
 FAMILIES = ["materials", "spheres", "animated", "noise", "envonly", "meshlight"]
 
 
-from path_tracing_amd.workloads import big_mesh_scene, displaced_grid, lookat_animation, quat  # noqa: E402,F401
+from path_tracing_amd import workloads  # noqa: E402
+from path_tracing_amd.workloads import displaced_grid, lookat_animation, quat  # noqa: E402,F401
+
+
+def big_mesh_scene(n, seed=1):
+    """The benchmark's mesh scene with the reference's tree (the workload itself comes without one)."""
+    s, cam = workloads.big_mesh_scene(n, seed)
+    s.build_bvh()
+    return s, cam
 
 
 QUAD_POS = np.array([[-1, -1, 0], [1, -1, 0], [-1, 1, 0], [1, 1, 0]], np.float32)

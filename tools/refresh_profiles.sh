@@ -4,7 +4,7 @@
 # own time limit and a failure ends the script.
 #   tools/refresh_profiles.sh [prefix, default r02]
 set -e
-P=${1:-r02}
+P=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p "$OUT"
@@ -23,12 +23,8 @@ timeout -k 10 300 python3 bench.py --workload textured --steps 1 --warmup 1 > "$
 echo textured done
 timeout -k 10 300 python3 bench.py --workload frames --steps 1 --warmup 1 > "$OUT/${P}_bench_frames.json" 2> "$OUT/frames.err"
 echo frames done
-timeout -k 10 300 python3 bench.py --workload frames --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_frames_hosttree.json" 2> "$OUT/frameshost.err"
-echo frames host tree done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mesh" -o mesh -- \
     python3 bench.py --workload mesh1000 --steps 1 --warmup 1 > "$OUT/${P}_bench_mesh1000.json" 2> "$OUT/mesh.err"
 echo mesh done
-timeout -k 10 300 python3 bench.py --workload mesh1000 --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_mesh1000_hosttree.json" 2> "$OUT/meshhost.err"
-echo mesh host tree done
-timeout -k 10 300 python3 bench.py --workload cornell --bvh host --steps 1 --warmup 1 > "$OUT/${P}_bench_cornell_hosttree.json" 2> "$OUT/cornellhost.err"
-echo cornell host tree done
+timeout -k 10 300 python3 bench.py --workload cornell --bvh file --steps 1 --warmup 1 > "$OUT/${P}_bench_cornell_filetree.json" 2> "$OUT/cornellfile.err"
+echo cornell with the tree of the scene file done

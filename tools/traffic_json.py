@@ -41,7 +41,7 @@ def main():
         kernels[k] = {"launches": n, "avg_us_under_pmc": us, "fetch_size_kib": fk, "write_size_kib": wk,
                       "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
     print(json.dumps({"workload": workload, "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of "
-                      "bench.py --steps 1 --warmup 0; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch",
+                      "bench.py --steps 1 --warmup 0 --pmc-pass (the launches of one timed step, nothing else); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch",
                       "kernels": kernels}, indent=1))
 
 
