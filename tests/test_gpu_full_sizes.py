@@ -1,5 +1,5 @@
 """The benchmark's other configurations at their full sizes, through properties that need no full-size render
-on the CPU: the 2 M-triangle mesh at 1920x1080, the textured multi-material OBJ scene at 3840x2160 with path depth 32
+on the CPU: the 2 M-triangle and the 8 M-triangle mesh at 1920x1080, the textured multi-material OBJ scene at 3840x2160 with path depth 32
 (also split over two scene handles), and a frame of the reference's animation scene at 1920x1080.  (The Cornell configuration's counterpart is
 test_gpu_parity.py::test_full_size_properties.)"""
 import ctypes as C
@@ -64,6 +64,48 @@ def test_two_million_triangles(oracle):
     assert np.mean(hits_ref_tree["a"][both] != hits_dev_tree["a"][both]) <= 1e-5
     assert np.mean(hits_ref_tree["surface"][both] != hits_dev_tree["surface"][both]) <= 1e-3
     assert np.mean(bits(again) != bits(fast)) <= 1e-3  # paths that met a tie go another way
+
+
+def test_eight_million_triangles(oracle):
+    """The mesh workload at 8 M triangles -- node rows and surfaces (256 + 384 MB) no longer fit the 256 MiB last-level
+    cache -- with the tree built on the device: both walks give the same 1080p image bit for bit; a window of primary
+    hits and of per-sample radiance equals the oracle's on the very same tree (copied out with pt_scene_get_bvh); a
+    tile and sample ranges of a render equal the same part of the whole; equal inputs give equal trees."""
+    from path_tracing_amd import workloads
+    s, cam = workloads.big_mesh_scene(2000)
+    assert len(s.surfaces) == 8000002
+    W, H = 1920, 1080
+    with pt.DeviceScene(s) as dev:
+        dev.build_bvh_device()
+        p = pt.make_params(W, H, 1, seed=7)
+        fast = dev.render(cam, p)
+        os.environ["PT_TRAVERSAL"] = "reference"
+        try:
+            slow = dev.render(cam, p)
+        finally:
+            del os.environ["PT_TRAVERSAL"]
+        assert same_bits(fast, slow)
+        assert np.isfinite(fast).all() and fast.mean() > 0.01
+        tile = np.zeros_like(fast)
+        dev.render(cam, pt.make_params(W, H, 1, seed=7, tile=(700, 400, 1100, 650)), out=tile)
+        assert same_bits(tile[400:650, 700:1100], fast[400:650, 700:1100])
+        q = pt.make_params(W, H, 2, seed=7, tile=(600, 300, 1240, 660))
+        whole = dev.render(cam, q)
+        parts = [dev.render(cam, pt.make_params(W, H, 2, seed=7, tile=(600, 300, 1240, 660), samples=r, flags=pt.abi.PT_RENDER_SUM_ONLY))
+                 for r in ((0, 3), (3, 4))]
+        assert np.allclose(((parts[0] + parts[1]) / 4.0)[300:660, 600:1240], whole[300:660, 600:1240], rtol=1e-5, atol=1e-6)
+        # the oracle on the same tree
+        s.nodes = dev.get_bvh()
+        assert len(s.nodes) == 2 * 8000002 - 1
+        d = s.desc()
+        window = pt.make_params(W, H, 1, seed=7, tile=(800, 500, 1120, 620))
+        hits = dev.primary_hits(cam, window)
+        assert hits.tobytes() == oracle.primary_hits(C.byref(d), cam, window, math_mode=1).tobytes()
+        small = pt.make_params(W, H, 2, seed=7, tile=(900, 520, 964, 552))
+        assert same_bits(dev.render_samples(cam, small), oracle.render_samples(C.byref(d), cam, small, math_mode=1))
+        dev.build_bvh_device()
+        assert dev.get_bvh().tobytes() == s.nodes.tobytes()
+        assert same_bits(dev.render(cam, p), fast)
 
 
 def test_textured_scene_at_4k(golden_dir, oracle):
