@@ -208,6 +208,7 @@ def main():
         torch.cuda.synchronize()
         bvh_build_ms = (time.perf_counter() - tb) * 1e3
     out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    out8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") if frames else None
     stream = torch.cuda.current_stream()
     # a range of the strata (512 of 23 x 23): the library's mean is over all sqrt_spp^2 strata, so take plain sums and
     # divide by the number of samples rendered
@@ -246,6 +247,10 @@ def main():
                                           flags=pt.abi.PT_RENDER_SUM_ONLY if partial else 0), out)
                     if partial:
                         out.div_(float(spp))
+                    # the frame as the reference's animation program stores it: 8-bit sRGB, top row first
+                    # (src/07/pathtracer-frames.cpp:235-236 -> color.hpp:84-98, imgsave.hpp:29-33), on the device
+                    pt.image_to_8bit_device(out.data_ptr(), W, H, out8.data_ptr(), device=local_rank,
+                                            stream_ptr=stream.cuda_stream)
                 else:
                     b, e = s_begin + srange[0], s_begin + srange[1]
                     if e > b:
