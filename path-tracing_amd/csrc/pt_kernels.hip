@@ -573,6 +573,9 @@ try {
     pt_scene* sc = new pt_scene;
     sc->device = device;
     sc->n_surfaces = d->n_surfaces;
+    sc->nMaterials = uint32_t(std::min<uint64_t>(d->n_materials, 0xFFFFFFFFu));
+    sc->nTextures = uint32_t(std::min<uint64_t>(d->n_textures, 0xFFFFFFFFu));
+    sc->nMeshes = uint32_t(std::min<uint64_t>(d->n_meshes, 0xFFFFFFFFu));
     sc->hasDynamic = hasDynamic;
     std::memset(&sc->dev, 0, sizeof(sc->dev));
     DevScene& dev = sc->dev;

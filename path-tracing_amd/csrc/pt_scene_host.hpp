@@ -202,6 +202,7 @@ struct pt_scene {
     void* buildArea = nullptr; // work area of pt_scene_build_bvh_device, kept between calls (not in owned)
     size_t buildCapacity = 0;
     uint64_t n_surfaces = 0;
+    uint32_t nMaterials = 0, nTextures = 0, nMeshes = 0; // entries of the material-side tables (see shadeHitsKernel)
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
     bool walkStatsOn = false; // launch the instrumented tracing kernels (pt_scene_count_walk)

@@ -1253,15 +1253,58 @@ __global__ void __launch_bounds__(kClassifyBlock, 8) classifyKernel(DevScene sc,
     }
 }
 
+// The material-side tables of a scene -- materials, their constant textures, the texture table, the meshes -- that
+// the lanes of the shading kernel index each with a number of their own: copies in LDS, made once per block, where
+// they fit (a few dozen materials: a few KB).  Every such look-up from memory is a gather that the address unit of a
+// compute unit works off a cache line per clock, and a material's record alone is several of them; from LDS they
+// cost a few clocks per wave.  Measured per launch of 32 M records: Cornell box 1200 -> 1142 us, the textured scene
+// 2030 -> 1884, the mesh 1032 -> 988, the animation 1612 -> 1598.  (The per-surface tables as well -- attributes,
+// plane normals, surface rows, spheres, animations, the list of lights -- made the kernel slower where they fit:
+// Cornell box 1203 -> 1321 us at 107 registers, the animation unchanged; those gathers fall on a handful of cache
+// lines and were cheap already, the copy per block and the registers cost more.  Tables that the whole wave reads
+// at one index, the loop over the lights, stay in memory: those are scalar loads.)
+struct ShadeTableCounts {
+    uint32_t materials, textures, meshes;
+};
+
+constexpr uint32_t padWords(uint32_t bytes) { return ((bytes / 4u) + 3u) & ~3u; } // in 4-byte words, whole 16-byte rows
+
+__host__ __device__ inline uint32_t shadeTableWords(const ShadeTableCounts& n)
+{
+    return padWords(n.materials * uint32_t(sizeof(pt_material))) + padWords(n.materials * 32u)
+        + padWords(n.textures * uint32_t(sizeof(pt_texture))) + padWords(n.meshes * uint32_t(sizeof(DevMesh)));
+}
+
+PT_DEV void shadeTablesToLds(const DevScene& sc, const ShadeTableCounts& n, uint32_t* lds, DevScene& ls)
+{
+    uint32_t off = 0;
+    auto take = [&](const void* src, uint32_t bytes) {
+        uint32_t* dst = lds + off;
+        const uint32_t* from = static_cast<const uint32_t*>(src);
+        for (uint32_t i = threadIdx.x; i < bytes / 4u; i += kShadeBlock)
+            dst[i] = from[i];
+        off += padWords(bytes);
+        return dst;
+    };
+    ls.materials = reinterpret_cast<const pt_material*>(take(sc.materials, n.materials * uint32_t(sizeof(pt_material))));
+    ls.matConst = reinterpret_cast<const float4*>(take(sc.matConst, n.materials * 32u));
+    ls.textures = reinterpret_cast<const pt_texture*>(take(sc.textures, n.textures * uint32_t(sizeof(pt_texture))));
+    ls.meshes = reinterpret_cast<const DevMesh*>(take(sc.meshes, n.meshes * uint32_t(sizeof(DevMesh))));
+}
+
 // The grid has blocksPerShard blocks for the front of each shard's list: the whole list (listCap / kShadeBlock), or
 // fewer once the host knows that no list can be longer (see runBatch).
+template <bool MAT>
 __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(DevScene sc, Pool pool, Pool next, PathParams pp,
                                                                        uint32_t* __restrict__ counters, int parity,
                                                                        float* __restrict__ samples, uint32_t shadowCap,
                                                                        FastDiv blocksPerShard,
-                                                                       unsigned long long* __restrict__ stats)
+                                                                       unsigned long long* __restrict__ stats,
+                                                                       ShadeTableCounts tableCounts)
 {
     __shared__ uint32_t lds[2 * (kShadeBlock / 64 + 1)];
+    extern __shared__ uint4 ldsTableRows[]; // (rows of 16 bytes: the tables are read with 16-byte LDS loads)
+    uint32_t* ldsTables = reinterpret_cast<uint32_t*>(ldsTableRows);
     // the block's entries lie inside one shard's list
     const uint32_t shard = blocksPerShard.div(blockIdx.x);
     const uint32_t first = (blockIdx.x - shard * blocksPerShard.d) * kShadeBlock; // within the list
@@ -1271,6 +1314,12 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
     const uint32_t entry = first + threadIdx.x;
     const bool valid = entry < fill;
     const uint32_t slot = valid ? pool.hitList[size_t(shard) * pool.listCap + entry] : 0u;
+    // `ls`: the scene with the material-side tables in LDS; `sc`: everything in memory
+    DevScene ls = sc;
+    if (MAT) {
+        shadeTablesToLds(sc, tableCounts, ldsTables, ls);
+        __syncthreads();
+    }
     bool finished = false;
     bool haveShadow = false, nullShadow = false;
     V3 shOrigin, shDir, shC, shBack = v3(0.0f);
@@ -1302,13 +1351,13 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
         hl.a = __uint_as_float(hw.y);
         hl.u = __uint_as_float(hw.z);
         hl.v = __uint_as_float(hw.w);
-        Hit hr = makeHit(sc, ray, hl);
+        Hit hr = makeHit(ls, ray, hl);
         MaterialValues mv;
-        Scatter sr = materialScatter<false>(sc, hr.material, ray, hr, rng, &mv);
+        Scatter sr = materialScatter<false>(ls, hr.material, ray, hr, rng, &mv);
         {
             // radiance += throughput * Le, on the path's sample: nothing to do for a surface that does not emit --
             // unless the throughput is no longer finite, when 0 * throughput is NaN and the reference's sum becomes NaN
-            const V3 le = materialLe(sc, hr.material, hr.backside);
+            const V3 le = materialLe(ls, hr.material, hr.backside);
             const bool emits = le.x != 0.0f || le.y != 0.0f || le.z != 0.0f;
             const bool finite = fabs_(throughput.x) < __builtin_huge_valf() && fabs_(throughput.y) < __builtin_huge_valf()
                 && fabs_(throughput.z) < __builtin_huge_valf();
@@ -1324,8 +1373,8 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
                 uint32_t lightIndex = uint32_t(rng.in01() * sc.n_lights);
                 if (lightIndex >= sc.n_lights)
                     lightIndex = sc.n_lights - 1;
-                const uint32_t lightSurf = sc.lights[lightIndex];
-                V3 lightDir = surfaceDirection<false>(sc, lightSurf, hr.position, ray.time, rng);
+                const uint32_t lightSurf = ls.lights[lightIndex];
+                V3 lightDir = surfaceDirection<false>(ls, lightSurf, hr.position, ray.time, rng);
                 // (the two sums over the lights draw no random numbers, so they can be taken together)
                 float lightsP, lightDirP;
                 uint32_t lightSide;
@@ -1333,8 +1382,8 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
                 nextThroughput = nextThroughput * powerHeuristicMIS(sr.p, lightsP);
                 if (lightDirP > 0.0f) {
                     // (a two-sided material scattered as one of its sides and answers scatterToDirection itself)
-                    Scatter lightSR = materialScatterToDirection(sc, hr.material, ray, hr, lightDir,
-                                                                 sc.materials[hr.material].type == PT_MAT_TWOSIDED ? nullptr : &mv);
+                    Scatter lightSR = materialScatterToDirection(ls, hr.material, ray, hr, lightDir,
+                                                                 ls.materials[hr.material].type == PT_MAT_TWOSIDED ? nullptr : &mv);
                     if (lightSR.p > 0.0f) {
                         float weight = powerHeuristicMIS(lightDirP, lightSR.p);
                         // everything of the contribution but the light's emission, which the
@@ -1350,15 +1399,15 @@ __global__ void __launch_bounds__(kShadeBlock, PT_SHADE_WAVES) shadeHitsKernel(D
                         // contribution * emission for the light's front and, if that side emits
                         // too, for its back
                         int lmat;
-                        if (fbits(sc.surf[3 * size_t(lightSurf) + 0].w) <= kTriDynamic)
-                            lmat = int(sc.surfAttr[lightSurf].w & 0xFFFFFFu);
+                        if (fbits(ls.surf[3 * size_t(lightSurf) + 0].w) <= kTriDynamic)
+                            lmat = int(ls.surfAttr[lightSurf].w & 0xFFFFFFu);
                         else
-                            lmat = sc.spheres[sc.surfAttr[lightSurf].x].material;
+                            lmat = ls.spheres[ls.surfAttr[lightSurf].x].material;
                         // (a black back side still matters if the product is NaN: NaN != 0)
-                        shBack = shC * materialLe(sc, lmat, true);
+                        shBack = shC * materialLe(ls, lmat, true);
                         if (shBack.x != 0.0f || shBack.y != 0.0f || shBack.z != 0.0f)
                             shLight |= kBackEmits;
-                        shC = shC * materialLe(sc, lmat, false);
+                        shC = shC * materialLe(ls, lmat, false);
                         // A shadow ray adds its contribution if its closest hit is the chosen light, by the side it
                         // arrives at.  The test it would make at that light's leaf has just been made for the light's
                         // pdf (same ray, same vertices, a wider interval): if that missed, or found the side whose
@@ -2053,6 +2102,34 @@ void launchTraceFor(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStre
     }
 }
 
+// The shading launch, with the scene's material-side tables in LDS where they fit (PT_NO_SHADE_LDS: never).
+constexpr uint32_t kShadeLdsLimit = 24 * 1024;
+
+size_t shadeTableBytes(const pt_scene* sc)
+{
+    if (std::getenv("PT_NO_SHADE_LDS") != nullptr)
+        return 0;
+    // (32-bit sizes inside: a scene anywhere near the limit of those is far beyond what fits)
+    if (sc->nMaterials >= (1u << 20) || sc->nTextures >= (1u << 20) || sc->nMeshes >= (1u << 20))
+        return 0;
+    const ShadeTableCounts n = { sc->nMaterials, sc->nTextures, sc->nMeshes };
+    const uint64_t bytes = uint64_t(shadeTableWords(n)) * 4u;
+    return bytes <= kShadeLdsLimit ? size_t(bytes) : 0;
+}
+
+void launchShade(pt_scene* sc, size_t ldsBytes, dim3 grid, hipStream_t stream, const Pool& cur, const Pool& next,
+                 const PathParams& pp, uint32_t* counters, int parity, float* samples, uint32_t shadowCap, FastDiv blocksPerShard,
+                 unsigned long long* stats)
+{
+    const ShadeTableCounts n = { sc->nMaterials, sc->nTextures, sc->nMeshes };
+    if (ldsBytes > 0)
+        hipLaunchKernelGGL(shadeHitsKernel<true>, grid, dim3(kShadeBlock), ldsBytes, stream, sc->dev, cur, next, pp, counters, parity,
+                           samples, shadowCap, blocksPerShard, stats, n);
+    else
+        hipLaunchKernelGGL(shadeHitsKernel<false>, grid, dim3(kShadeBlock), 0, stream, sc->dev, cur, next, pp, counters, parity,
+                           samples, shadowCap, blocksPerShard, stats, n);
+}
+
 // Run one batch of samples [b.sFirst, b.sFirst + b.nS) of every pixel of the tile into the sample buffer.
 int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch& b, const Pool pools[2], hipStream_t stream)
 {
@@ -2066,6 +2143,7 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
     const bool lds = sceneFitsLds(sc);
     const uint32_t shadowCap = shadowCapOf(nSlots);
     const dim3 block(256);
+    const size_t shadeLds = shadeTableBytes(sc);
     // the first tracing launch has no generateKernel before it: nothing to add to the path numbers
     for (uint32_t q = 0; q < kShards; q++)
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.counters + (kCtrLive + q) * kCtrStride),
@@ -2095,9 +2173,8 @@ int runBatch(pt_scene* sc, WavefrontBuffers& w, const RenderArgs& a, const Batch
                                w.counters, w.samples, FastDiv(classifyBlocks));
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kShade, stream);
-            hipLaunchKernelGGL(shadeHitsKernel, dim3(shadeBlocks * kShards), dim3(kShadeBlock), 0, stream, sc->dev, cur, next, a.pp,
-                               w.counters, parity, w.samples, shadowCap, FastDiv(shadeBlocks),
-                               sc->walkStatsOn ? w.walkStats : nullptr);
+            launchShade(sc, shadeLds, dim3(shadeBlocks * kShards), stream, cur, next, a.pp, w.counters, parity, w.samples, shadowCap,
+                        FastDiv(shadeBlocks), sc->walkStatsOn ? w.walkStats : nullptr);
             sc->kt.end(stream);
             sc->kt.begin(KernelTimes::kGenerate, stream);
             hipLaunchKernelGGL(generateKernel, dim3(generateBlocks * kShards), block, 0, stream, sc->dev, next, a, b, w.counters,
