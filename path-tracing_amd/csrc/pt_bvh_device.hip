@@ -1071,6 +1071,7 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
     // refuses to render rather than one with a partly rewritten tree
     scene->dev.n_nodes = 0;
     scene->dev.wide = nullptr;
+    scene->dev.quad = nullptr;
     const DevScene& sc = scene->dev;
     const uint32_t leafBlocks = (uint32_t(n) + kBlock - 1) / kBlock;
 
@@ -1118,7 +1119,9 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
         HIP_TRY(hipStreamSynchronize(stream));
         scene->dev.n_nodes = 1;
         scene->dev.wide = scene->wide; // no inner node: no row is ever read
-        const int rcLinks = ptWavefrontBuildWalkLinks(scene, t0, stream);
+        int rcLinks = ptWavefrontBuildWalkLinks(scene, t0, stream);
+        if (rcLinks == PT_OK)
+            rcLinks = ptBuildQuadRows(scene, stream);
         if (rcLinks != PT_OK) {
             scene->dev.n_nodes = 0;
             return rcLinks;
@@ -1248,7 +1251,9 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
     }
     scene->dev.wide = gridOk ? scene->wide : nullptr; // without rows: storage-order walk only
     scene->dev.n_nodes = uint32_t(2 * n - 1);
-    const int rcLinks = ptWavefrontBuildWalkLinks(scene, t0, stream);
+    int rcLinks = ptWavefrontBuildWalkLinks(scene, t0, stream);
+    if (rcLinks == PT_OK)
+        rcLinks = ptBuildQuadRows(scene, stream);
     if (rcLinks != PT_OK) {
         scene->dev.n_nodes = 0;
         return rcLinks;

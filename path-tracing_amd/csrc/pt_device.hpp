@@ -23,6 +23,8 @@ using namespace ptv;
 constexpr uint32_t kInner = 0xFFFFFFFFu; // "no surface": a node step that did not end on a hit leaf
 constexpr uint32_t kInnerBit = 0x80000000u; // DevNode.leaf of an inner node: kInnerBit | index of its second child
 constexpr uint32_t kLeafRowBit = 0x40000000u; // in a link of the `wide` table, see DevScene
+constexpr uint32_t kQuadNoLink = 0x7FFFFFFFu; // link of an unused slot of a `quad` row (as a leaf link this would be
+                                              // node 2^30 - 1: the builders stop below)
 constexpr uint32_t kMeshMask = 0x00FFFFFFu;  // surface row 1, word 3: mesh number | material type << 24
 
 // surface kinds (SurfRec word 3 of row 0)
@@ -62,6 +64,10 @@ struct DevScene {
                              // number, or a static triangle's surface id (its box is that of its vertices), or
                              // kLeafRowBit | node number (box and surface are in that row of `nodes`).  Null
                              // if the boxes do not fit the grid (non-finite coordinates).
+    const uint4* quad;       // the four-wide form of `wide`, or null: per row 4 x uint4 = the boxes of up to four
+                             // descendants of an inner node (3 words each, as above), then their four links;
+                             // kInnerBit | row number for an inner one (rows come after the rows that lead to
+                             // them, row 0 stands for the root), kQuadNoLink in a slot not used
     float qbase[3], qstep[3]; // grid coordinate q of axis a stands for fmaf(q, qstep[a], qbase[a])
     const float4* surf;
     const uint4* surfAttr;   // per surface: triangles (vertex 0, 1, 2 in the vertex streams, material | flags << 24);

@@ -194,6 +194,39 @@ int buildDeviceNodes(const pt_bvh_node* nodes, uint64_t n, std::vector<float4>& 
     return PT_OK;
 }
 
+// grid coordinate at or below / at or above a value, checked with the expression the device decodes it with
+bool gridCoordBelow(float base, float step, float v, uint32_t& q)
+{
+    if (!std::isfinite(v) || v < base)
+        return false;
+    double est = std::floor((double(v) - double(base)) / double(step));
+    int64_t k = int64_t(std::min(std::max(est, 0.0), 65535.0));
+    while (k > 0 && std::fmaf(float(k), step, base) > v)
+        k--;
+    while (k < 65535 && std::fmaf(float(k + 1), step, base) <= v)
+        k++;
+    if (std::fmaf(float(k), step, base) > v)
+        return false;
+    q = uint32_t(k);
+    return true;
+}
+
+bool gridCoordAbove(float base, float step, float v, uint32_t& q)
+{
+    if (!std::isfinite(v))
+        return false;
+    double est = std::ceil((double(v) - double(base)) / double(step));
+    int64_t k = int64_t(std::min(std::max(est, 0.0), 65535.0));
+    while (k < 65535 && std::fmaf(float(k), step, base) < v)
+        k++;
+    while (k > 0 && std::fmaf(float(k - 1), step, base) >= v)
+        k--;
+    if (std::fmaf(float(k), step, base) < v)
+        return false;
+    q = uint32_t(k);
+    return true;
+}
+
 // The table of the nearer-child-first walk: per inner node (numbered in storage order among the
 // inner nodes) one 32-byte row with the boxes of both children on a 16-bit grid over the root
 // box and the children's links (see DevScene::wide).  A grid box always contains the exact one:
@@ -231,35 +264,8 @@ bool buildWideNodes(const pt_bvh_node* nodes, uint64_t n, const std::vector<floa
             return false;
         step[a] = st;
     }
-    // grid coordinate at or below / at or above a value
-    auto below = [&](int a, float v, uint32_t& q) {
-        if (!std::isfinite(v) || v < base[a])
-            return false;
-        double est = std::floor((double(v) - double(base[a])) / double(step[a]));
-        int64_t k = int64_t(std::min(std::max(est, 0.0), 65535.0));
-        while (k > 0 && std::fmaf(float(k), step[a], base[a]) > v)
-            k--;
-        while (k < 65535 && std::fmaf(float(k + 1), step[a], base[a]) <= v)
-            k++;
-        if (std::fmaf(float(k), step[a], base[a]) > v)
-            return false;
-        q = uint32_t(k);
-        return true;
-    };
-    auto above = [&](int a, float v, uint32_t& q) {
-        if (!std::isfinite(v))
-            return false;
-        double est = std::ceil((double(v) - double(base[a])) / double(step[a]));
-        int64_t k = int64_t(std::min(std::max(est, 0.0), 65535.0));
-        while (k < 65535 && std::fmaf(float(k), step[a], base[a]) < v)
-            k++;
-        while (k > 0 && std::fmaf(float(k - 1), step[a], base[a]) >= v)
-            k--;
-        if (std::fmaf(float(k), step[a], base[a]) < v)
-            return false;
-        q = uint32_t(k);
-        return true;
-    };
+    auto below = [&](int a, float v, uint32_t& q) { return gridCoordBelow(base[a], step[a], v, q); };
+    auto above = [&](int a, float v, uint32_t& q) { return gridCoordAbove(base[a], step[a], v, q); };
     std::vector<uint32_t> innerNumber(n, 0);
     uint32_t nInner = 0;
     for (uint64_t k = 0; k < n; k++)
@@ -298,6 +304,117 @@ bool buildWideNodes(const pt_bvh_node* nodes, uint64_t n, const std::vector<floa
         const size_t r = 2 * size_t(innerNumber[k]);
         out[r + 0] = make_uint4(w[0], w[1], w[2], w[3]);
         out[r + 1] = make_uint4(w[4], w[5], linkOf(child[0]), linkOf(child[1]));
+    }
+    return true;
+}
+
+// The table of the four-wide form of that walk (DevScene::quad), from the device's node table.  A row stands for an
+// inner node and holds up to four of its descendants: beginning with its two children, the inner node with the
+// largest box surface among them is replaced by its own two children until there are four (or only leaves): the
+// boxes a ray is most likely to enter anyway are the ones not worth a step of their own.  Rows are numbered in
+// pre-order of the nodes they stand for, so a row's children rows come after it.  Same grid, same rounding and same
+// three kinds of link as the two-wide rows; a slot that is not used holds kQuadNoLink and a box nothing enters.
+// Returns false if a box cannot be put on the grid.
+bool buildQuadRows(const float4* nodes, uint64_t n, const std::vector<float4>& surf, const float base[3], const float step[3],
+                   std::vector<uint4>& out)
+{
+    out.clear();
+    if (n == 0 || n >= kLeafRowBit)
+        return n == 0;
+    auto leafWord = [&](uint64_t k) { return __builtin_bit_cast(uint32_t, nodes[2 * k + 1].w); };
+    auto lo = [&](uint64_t k, int a) { return a == 0 ? nodes[2 * k].x : a == 1 ? nodes[2 * k].y : nodes[2 * k].z; };
+    auto hi = [&](uint64_t k, int a) { return a == 0 ? nodes[2 * k].w : a == 1 ? nodes[2 * k + 1].x : nodes[2 * k + 1].y; };
+    auto area = [&](uint64_t k) {
+        const double dx = double(hi(k, 0)) - double(lo(k, 0)), dy = double(hi(k, 1)) - double(lo(k, 1)), dz = double(hi(k, 2)) - double(lo(k, 2));
+        return dx * dy + dy * dz + dz * dx;
+    };
+    if (!(leafWord(0) & kInnerBit))
+        return true; // a single leaf: no row is ever read
+    // pass 1: which nodes get rows, their numbers, their children
+    struct Row {
+        uint32_t node, child[4], nChildren;
+    };
+    std::vector<Row> rows;
+    std::vector<uint32_t> rowOf(n, 0xFFFFFFFFu), todo;
+    todo.push_back(0);
+    while (!todo.empty()) {
+        const uint32_t k = todo.back();
+        todo.pop_back();
+        Row r;
+        r.node = k;
+        r.child[0] = k + 1;
+        r.child[1] = leafWord(k) & ~kInnerBit;
+        r.nChildren = 2;
+        while (r.nChildren < 4) {
+            int pick = -1;
+            double pickArea = -1.0;
+            for (uint32_t c = 0; c < r.nChildren; c++)
+                if ((leafWord(r.child[c]) & kInnerBit) && area(r.child[c]) > pickArea) {
+                    pick = int(c);
+                    pickArea = area(r.child[c]);
+                }
+            if (pick < 0)
+                break;
+            const uint32_t parent = r.child[pick];
+            r.child[pick] = parent + 1;
+            r.child[r.nChildren++] = leafWord(parent) & ~kInnerBit;
+        }
+        for (uint32_t c = 0; c < r.nChildren; c++)
+            if (r.child[c] >= n)
+                return false;
+        rowOf[k] = uint32_t(rows.size());
+        rows.push_back(r);
+        for (int c = int(r.nChildren) - 1; c >= 0; c--)
+            if (leafWord(r.child[c]) & kInnerBit)
+                todo.push_back(r.child[c]);
+    }
+    // pass 2: the rows
+    out.assign(4 * rows.size(), make_uint4(0, 0, 0, 0));
+    for (size_t i = 0; i < rows.size(); i++) {
+        const Row& r = rows[i];
+        uint32_t w[12], link[4];
+        for (uint32_t c = 0; c < 4; c++) {
+            if (c >= r.nChildren) {
+                w[3 * c + 0] = 0xFFFFFFFFu; // lo.x = lo.y = 65535
+                w[3 * c + 1] = 0x0000FFFFu; // lo.z = 65535, hi.x = 0
+                w[3 * c + 2] = 0u;          // hi.y = hi.z = 0
+                link[c] = kQuadNoLink;
+                continue;
+            }
+            const uint64_t at = r.child[c];
+            uint32_t qlo[3], qhi[3];
+            for (int a = 0; a < 3; a++)
+                if (!gridCoordBelow(base[a], step[a], lo(at, a), qlo[a]) || !gridCoordAbove(base[a], step[a], hi(at, a), qhi[a]))
+                    return false;
+            w[3 * c + 0] = qlo[0] | (qlo[1] << 16);
+            w[3 * c + 1] = qlo[2] | (qhi[0] << 16);
+            w[3 * c + 2] = qhi[1] | (qhi[2] << 16);
+            const uint32_t l = leafWord(at);
+            if (l & kInnerBit) {
+                if (rowOf[at] == 0xFFFFFFFFu || rowOf[at] <= i)
+                    return false;
+                link[c] = kInnerBit | rowOf[at];
+            } else {
+                link[c] = kLeafRowBit | uint32_t(at);
+                if (3 * size_t(l) + 2 < surf.size() && __builtin_bit_cast(uint32_t, surf[3 * size_t(l)].w) == kTriStatic) {
+                    const float4 &A = surf[3 * size_t(l)], &B = surf[3 * size_t(l) + 1], &C = surf[3 * size_t(l) + 2];
+                    const float tlo[3] = { std::min(A.x, std::min(B.x, C.x)), std::min(A.y, std::min(B.y, C.y)),
+                                           std::min(A.z, std::min(B.z, C.z)) };
+                    const float thi[3] = { std::max(A.x, std::max(B.x, C.x)), std::max(A.y, std::max(B.y, C.y)),
+                                           std::max(A.z, std::max(B.z, C.z)) };
+                    bool same = true;
+                    for (int a = 0; a < 3; a++)
+                        same = same && __builtin_bit_cast(uint32_t, tlo[a]) == __builtin_bit_cast(uint32_t, lo(at, a))
+                            && __builtin_bit_cast(uint32_t, thi[a]) == __builtin_bit_cast(uint32_t, hi(at, a));
+                    if (same)
+                        link[c] = l;
+                }
+            }
+        }
+        out[4 * i + 0] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[4 * i + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        out[4 * i + 2] = make_uint4(w[8], w[9], w[10], w[11]);
+        out[4 * i + 3] = make_uint4(link[0], link[1], link[2], link[3]);
     }
     return true;
 }
@@ -386,6 +503,34 @@ int launchRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t
 }
 
 } // namespace
+
+int ptBuildQuadRows(pt_scene* scene, hipStream_t stream)
+{
+    scene->dev.quad = nullptr;
+    // PT_QUAD_ROWS=1: trace scenes in memory with the four-wide walk
+    const char* env = std::getenv("PT_QUAD_ROWS");
+    if (!env || env[0] == '0' || !scene->dev.wide || scene->dev.n_nodes < 3)
+        return PT_OK;
+    const uint64_t n = scene->dev.n_nodes;
+    std::vector<float4> nodes(2 * n);
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(nodes.data(), scene->nodes, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<uint4> rows;
+    if (!buildQuadRows(nodes.data(), n, scene->hostSurf, scene->dev.qbase, scene->dev.qstep, rows) || rows.empty())
+        return PT_OK;
+    const size_t room = 4 * size_t(scene->n_surfaces - 1);
+    if (rows.size() > room)
+        return fail(PT_ERR_LIMIT, "four-wide rows: more rows than inner nodes");
+    if (!scene->quad) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, room * sizeof(uint4)));
+        scene->owned.push_back(p);
+        scene->quad = static_cast<uint4*>(p);
+    }
+    HIP_TRY(hipMemcpy(scene->quad, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    scene->dev.quad = scene->quad;
+    return PT_OK;
+}
 
 extern "C" {
 
@@ -660,7 +805,39 @@ try {
         return fail(PT_ERR_DEVICE, "cannot create timing events");
     }
     if ((rc = ptWavefrontBuildWalkLinks(sc, 0.0f, nullptr)) != PT_OK) return bail(rc);
+    if ((rc = ptBuildQuadRows(sc, nullptr)) != PT_OK) return bail(rc);
     *out_scene = sc;
+    return PT_OK;
+} catch (...) {
+    return ptint::caught();
+}
+
+int pt_bvh_quad_rows(const pt_bvh_node* nodes, uint64_t n_nodes, uint32_t* out_rows, uint64_t capacity_rows,
+                     uint64_t* out_n_rows, float out_base[3], float out_step[3])
+try {
+    if (!nodes || !out_rows || !out_n_rows || !out_base || !out_step)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_nodes == 0 || n_nodes % 2 == 0)
+        return fail(PT_ERR_INVALID_ARGUMENT, "node count is not 2 * surfaces - 1");
+    for (uint64_t i = 0; i < n_nodes; i++) {
+        const uint64_t link = nodes[i].link;
+        if (link % 2 == 0 ? link / 2 >= (n_nodes + 1) / 2 : (link / 2 <= i + 1 || link / 2 >= n_nodes))
+            return fail(PT_ERR_INVALID_ARGUMENT, "node " + std::to_string(i) + " has a bad link");
+    }
+    std::vector<float4> dn;
+    const int rc = buildDeviceNodes(nodes, n_nodes, dn);
+    if (rc != PT_OK)
+        return rc;
+    std::vector<uint4> two, rows;
+    const std::vector<float4> noSurfaces;
+    if (!buildWideNodes(nodes, n_nodes, noSurfaces, two, out_base, out_step)
+        || !buildQuadRows(dn.data(), n_nodes, noSurfaces, out_base, out_step, rows))
+        return fail(PT_ERR_INVALID_ARGUMENT, "the boxes do not fit a grid over the root box");
+    *out_n_rows = rows.size() / 4;
+    if (rows.size() / 4 > capacity_rows)
+        return fail(PT_ERR_LIMIT, "more rows than the output holds");
+    if (!rows.empty())
+        std::memcpy(out_rows, rows.data(), rows.size() * sizeof(uint4));
     return PT_OK;
 } catch (...) {
     return ptint::caught();
@@ -695,6 +872,8 @@ try {
         scene->dev.wide = nullptr;
     }
     rc = ptWavefrontBuildWalkLinks(scene, 0.0f, nullptr);
+    if (rc == PT_OK)
+        rc = ptBuildQuadRows(scene, nullptr);
     if (rc != PT_OK) {
         scene->dev.n_nodes = 0;
         return rc;

@@ -197,6 +197,7 @@ struct pt_scene {
     std::vector<void*> owned; // every device allocation of the scene
     float4* nodes = nullptr;  // also in owned; kept for pt_scene_update_bvh
     uint4* wide = nullptr;    // likewise (room for n_surfaces - 1 rows)
+    uint4* quad = nullptr;    // rows of the four-wide walk, if made (room for n_surfaces - 1 rows of 4 x uint4)
     uint2* walkLinks = nullptr; // likewise, allocated when first needed: link table of the walk from LDS (room for any tree)
     std::vector<float4> hostSurf; // the surface table as uploaded: which leaves have the box of their vertices
     void* buildArea = nullptr; // work area of pt_scene_build_bvh_device, kept between calls (not in owned)
@@ -257,4 +258,6 @@ int ptWavefrontReadWalkStats(pt_scene* scene, pt_walk_counters* out);
 int ptWavefrontStaticSetup(int device);
 // (re)make DevScene::walkLinks for the tree the scene has now; the caller holds the scene's lock
 int ptWavefrontBuildWalkLinks(pt_scene* scene, float time, hipStream_t stream);
+// the rows of the four-wide walk for the tree the scene holds now (dev.nodes, dev.n_nodes, the grid of dev.wide)
+int ptBuildQuadRows(pt_scene* scene, hipStream_t stream);
 int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);

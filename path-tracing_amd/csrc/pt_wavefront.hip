@@ -712,13 +712,63 @@ PT_DEV void flushRetries(const Pool& pool, uint32_t* counters, uint32_t waveIdx,
 #define PT_ORDERED_BLOCK 256
 #endif
 constexpr uint32_t kOrderedBlock = PT_ORDERED_BLOCK; // threads per block of traceOrderedKernel
-template <bool DYN, bool STATS>
+#ifndef PT_STACK_DEPTH_QUAD
+#define PT_STACK_DEPTH_QUAD 16
+#endif
+#ifndef PT_QUAD_GATE16
+#define PT_QUAD_GATE16 1
+#endif
+
+// one box of a row: three words on the grid (see DevScene::wide) against the ray
+PT_DEV bool gridBoxEntry(uint32_t w0, uint32_t w1, uint32_t w2, V3 base, V3 step, const Ray& ray, float cull, float& entry)
+{
+    const V3 lo = v3(fmaf(float(w0 & 0xFFFFu), step.x, base.x), fmaf(float(w0 >> 16), step.y, base.y), fmaf(float(w1 & 0xFFFFu), step.z, base.z));
+    const V3 hi = v3(fmaf(float(w1 >> 16), step.x, base.x), fmaf(float(w2 & 0xFFFFu), step.y, base.y), fmaf(float(w2 >> 16), step.z, base.z));
+    return aabbEntry(lo, hi, ray, 0.0001f, cull, entry);
+}
+
+// put two (entry distance, link) pairs in order of distance
+PT_DEV void nearerFirst(float& ea, uint32_t& la, float& eb, uint32_t& lb)
+{
+    const bool swap = eb < ea;
+    const float e0 = swap ? eb : ea, e1 = swap ? ea : eb;
+    const uint32_t l0 = swap ? lb : la, l1 = swap ? la : lb;
+    ea = e0;
+    eb = e1;
+    la = l0;
+    lb = l1;
+}
+
+// WIDTH 2: rows of DevScene::wide; WIDTH 4: rows of DevScene::quad (up to four boxes per step: half the steps, each
+// one trip to memory, for the same number of box tests)
+template <int WIDTH, bool DYN, bool STATS>
 __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedKernel(DevScene sc, Pool pool, uint32_t* __restrict__ counters, int parity,
                                                           float* __restrict__ samples, uint32_t shadowCap, uint32_t slotWaves,
                                                           int taken, unsigned long long* __restrict__ stats)
 {
     uint32_t nRays = 0, nShadowRays = 0, nRows = 0, nLeafRows = 0, nTests = 0, nAmbiguous = 0;
-    __shared__ uint2 stack[kStackDepth][kOrderedBlock];
+    constexpr uint32_t kDepth = WIDTH == 4 ? uint32_t(PT_STACK_DEPTH_QUAD) : kStackDepth;
+    // A kept node is (link, gate).  The four-wide walk keeps up to three per step, so its stacks are deeper and an
+    // entry is 6 bytes: the gate cut to its upper 16 bits, which rounds it down -- a kept node's gate only decides
+    // whether the node is still visited when its turn comes (a lower gate visits it a little more often), and the
+    // gate that the rule for ambiguous results uses is set anew from the exact box of every leaf.
+    constexpr bool kGate16 = WIDTH == 4 && PT_QUAD_GATE16 != 0;
+    __shared__ uint2 stack[kGate16 ? 1 : kDepth][kGate16 ? 1 : kOrderedBlock];
+    __shared__ uint32_t stackLink[kGate16 ? kDepth : 1][kGate16 ? kOrderedBlock : 1];
+    __shared__ uint16_t stackGate[kGate16 ? kDepth : 1][kGate16 ? kOrderedBlock : 1];
+    auto keep = [&](uint32_t at, uint32_t l, float g) {
+        if (kGate16) {
+            stackLink[at][threadIdx.x] = l;
+            stackGate[at][threadIdx.x] = uint16_t(fbits(g) >> 16);
+        } else {
+            stack[at][threadIdx.x] = make_uint2(l, fbits(g));
+        }
+    };
+    auto kept = [&](uint32_t at) {
+        if (kGate16)
+            return make_uint2(stackLink[at][threadIdx.x], uint32_t(stackGate[at][threadIdx.x]) << 16);
+        return stack[at][threadIdx.x];
+    };
     __shared__ uint2 retryBuf[kOrderedBlock / 64u][kRetryBuf]; // per wave: ambiguous rays waiting to go to the retry list
     uint32_t nRetry = 0;                     // entries in this wave's part (the same in every lane)
     if (blockIdx.x == 0)
@@ -734,7 +784,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
     fillsOfParts(counters, parity, sFill);
     __syncthreads();
     const float4* __restrict__ nodes = sc.nodes;
-    const uint4* __restrict__ wide = sc.wide;
+    const uint4* __restrict__ wide = WIDTH == 4 ? sc.quad : sc.wide;
     const float4* __restrict__ surf = sc.surf;
     const uint32_t waveIdx = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * kOrderedBlock + threadIdx.x) >> 6)));
     const uint32_t lane = laneId();
@@ -858,7 +908,69 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
             while (walkers != 0) {
 #pragma unroll
                 for (int rep = 0; rep < PT_ORDERED_STEPS_PER_VOTE; rep++) {
-                if (int32_t(link) < 0) {
+                if (WIDTH == 4 && int32_t(link) < 0) {
+                    // test the boxes of the row, go to the nearest one that is hit, keep the others, the nearest on top
+                    const uint32_t k = link & ~kInnerBit;
+                    const uint4 q0 = wide[4 * size_t(k) + 0], q1 = wide[4 * size_t(k) + 1], q2 = wide[4 * size_t(k) + 2];
+                    const uint4 q3 = wide[4 * size_t(k) + 3];
+                    if (STATS)
+                        nRows++;
+                    const V3 base = v3(sc.qbase[0], sc.qbase[1], sc.qbase[2]), step = v3(sc.qstep[0], sc.qstep[1], sc.qstep[2]);
+                    float e0, e1, e2, e3;
+                    uint32_t l0 = q3.x, l1 = q3.y, l2 = q3.z, l3 = q3.w;
+                    const bool h0 = gridBoxEntry(q0.x, q0.y, q0.z, base, step, ray, cull, e0) && l0 != kQuadNoLink;
+                    const bool h1 = gridBoxEntry(q0.w, q1.x, q1.y, base, step, ray, cull, e1) && l1 != kQuadNoLink;
+                    const bool h2 = gridBoxEntry(q1.z, q1.w, q2.x, base, step, ray, cull, e2) && l2 != kQuadNoLink;
+                    const bool h3 = gridBoxEntry(q2.y, q2.z, q2.w, base, step, ray, cull, e3) && l3 != kQuadNoLink;
+                    // a box that is not hit goes to the end
+                    e0 = h0 ? e0 : __builtin_huge_valf();
+                    e1 = h1 ? e1 : __builtin_huge_valf();
+                    e2 = h2 ? e2 : __builtin_huge_valf();
+                    e3 = h3 ? e3 : __builtin_huge_valf();
+                    l0 = h0 ? l0 : kNoLink;
+                    l1 = h1 ? l1 : kNoLink;
+                    l2 = h2 ? l2 : kNoLink;
+                    l3 = h3 ? l3 : kNoLink;
+                    nearerFirst(e0, l0, e1, l1);
+                    nearerFirst(e2, l2, e3, l3);
+                    nearerFirst(e0, l0, e2, l2);
+                    nearerFirst(e1, l1, e3, l3);
+                    nearerFirst(e1, l1, e2, l2);
+                    // when room runs out the farthest ones are left out (the result stands if they turn out to lie
+                    // beyond the limit anyway)
+                    const uint32_t room = kDepth - top;
+                    if (l3 != kNoLink) {
+                        const float g = fmaxf(gate, e3);
+                        if (room >= 3u) {
+                            keep(top, l3, g);
+                            top++;
+                        } else {
+                            dropGate = fminf(dropGate, g);
+                        }
+                    }
+                    if (l2 != kNoLink) {
+                        const float g = fmaxf(gate, e2);
+                        if (room >= 2u) {
+                            keep(top, l2, g);
+                            top++;
+                        } else {
+                            dropGate = fminf(dropGate, g);
+                        }
+                    }
+                    if (l1 != kNoLink) {
+                        const float g = fmaxf(gate, e1);
+                        if (room >= 1u) {
+                            keep(top, l1, g);
+                            top++;
+                        } else {
+                            dropGate = fminf(dropGate, g);
+                        }
+                    }
+                    if (l0 != kNoLink)
+                        gate = fmaxf(gate, e0);
+                    link = l0; // kNoLink: nothing below, take the next kept node
+                }
+                if (WIDTH == 2 && int32_t(link) < 0) {
                     const uint32_t k = link & ~kInnerBit;
                     const uint4 q0 = wide[2 * k + 0], q1 = wide[2 * k + 1];
                     if (STATS)
@@ -878,8 +990,8 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     const float g1 = fmaxf(gate, e1), g2 = fmaxf(gate, e2);
                     const bool firstNear = e1 <= e2;
                     if (h1 && h2) {
-                        if (top < kStackDepth) {
-                            stack[top][threadIdx.x] = make_uint2(firstNear ? q1.w : q1.z, fbits(firstNear ? g2 : g1));
+                        if (top < kDepth) {
+                            keep(top, firstNear ? q1.w : q1.z, firstNear ? g2 : g1);
                             top++;
                         } else {
                             // no room: leave the farther subtree out; the result stands if it turns
@@ -900,7 +1012,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                 if (link == kNoLink) {
                     while (top > 0) {
                         top--;
-                        const uint2 e = stack[top][threadIdx.x];
+                        const uint2 e = kept(top);
                         if (!(__uint_as_float(e.y) > cull)) {
                             link = e.x;
                             gate = __uint_as_float(e.y);
@@ -978,7 +1090,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
             link = kNoLink;
             while (top > 0) {
                 top--;
-                const uint2 e = stack[top][threadIdx.x];
+                const uint2 e = kept(top);
                 if (!(__uint_as_float(e.y) > cull)) {
                     link = e.x;
                     gate = __uint_as_float(e.y);
@@ -2014,6 +2126,16 @@ int ptWavefrontBuildWalkLinks(pt_scene* scene, float time, hipStream_t stream)
 
 namespace {
 
+// blocks of a kernel that a compute unit holds at once (at least 1: also the answer if the runtime cannot say)
+template <typename K>
+int residentBlocks(K kernel, uint32_t blockSize)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, int(blockSize), 0) != hipSuccess || n < 1)
+        n = 1;
+    return n;
+}
+
 // the tracing step of one iteration
 template <bool DYN, bool LDS, bool STATS>
 void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_t stream, int parity)
@@ -2039,10 +2161,18 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         sc->kt.begin(KernelTimes::kTraceOrdered, stream);
         // runs taken from counters by as many waves as the chip holds at once (PT_TRACE_RUNS=fixed: a wave per run)
         const uint32_t allBlocks = (slotWaves + shadowWaves) / (kOrderedBlock / 64u);
-        const uint32_t held = uint32_t(sc->computeUnits) * 4u * PT_ORDERED_WAVES / (kOrderedBlock / 64u);
+        const bool quad = sc->dev.quad != nullptr;
+        // (blocks per compute unit: what registers and the stacks in LDS allow)
+        static const int blocksPerUnit[2] = { residentBlocks(traceOrderedKernel<2, DYN, STATS>, kOrderedBlock),
+                                              residentBlocks(traceOrderedKernel<4, DYN, STATS>, kOrderedBlock) };
+        const uint32_t held = uint32_t(sc->computeUnits) * uint32_t(blocksPerUnit[quad ? 1 : 0]);
         const bool taken = !fixedRuns && held < allBlocks;
-        hipLaunchKernelGGL((traceOrderedKernel<DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, sc->dev,
-                           pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
+        if (quad)
+            hipLaunchKernelGGL((traceOrderedKernel<4, DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, sc->dev,
+                               pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
+        else
+            hipLaunchKernelGGL((traceOrderedKernel<2, DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, sc->dev,
+                               pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
         // a multiple of kRetryShards blocks: a few per sub-list, more only for large pools
         const uint32_t perList = std::min<uint32_t>(32u, std::max<uint32_t>(1u, pool.retryCap / 1024u));

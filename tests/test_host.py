@@ -55,6 +55,82 @@ def test_bvh_structure_invariants():
             assert np.all(nodes["lo"][i] <= nodes["lo"][child]) and np.all(nodes["hi"][i] >= nodes["hi"][child])
 
 
+def _quad_rows(nodes):
+    L = pt.lib()
+    n = len(nodes)
+    rows = np.zeros(((n - 1) // 2 + 1, 16), np.uint32)
+    n_rows = C.c_uint64(0)
+    base, step = (C.c_float * 3)(), (C.c_float * 3)()
+    L.pt_bvh_quad_rows.restype = C.c_int
+    rc = L.pt_bvh_quad_rows(nodes.ctypes.data_as(C.c_void_p), C.c_uint64(n), rows.ctypes.data_as(C.c_void_p),
+                            C.c_uint64(len(rows)), C.byref(n_rows), base, step)
+    assert rc == 0, L.pt_last_error().decode()
+    return rows[:n_rows.value], np.array(base[:], np.float32), np.array(step[:], np.float32)
+
+
+@pytest.mark.parametrize("which", ["mesh", "cornell"])
+def test_four_wide_rows_cover_the_tree(which, golden_dir):
+    """The rows of the four-wide walk, made on the host from the reference's tree: every leaf is reached exactly once
+    from row 0, rows lead only to later rows, a slot's grid box contains the node's box, a row with a free slot has no
+    inner node left to open, and the node opened at every step is the one with the largest box surface."""
+    if which == "mesh":
+        s, cam = scenes.big_mesh_scene(20)
+    else:
+        s = pt.LoadedScene(os.path.join(golden_dir, "cornell.ptscene"))
+    nodes = s.nodes if which == "mesh" else s.nodes()
+    n = len(nodes)
+    rows, base, step = _quad_rows(nodes)
+    INNER, LEAFROW, NOLINK = 0x80000000, 0x40000000, 0x7FFFFFFF
+    is_inner = nodes["link"] % 2 == 1
+    second = (nodes["link"] // 2).astype(np.int64)
+
+    def area(k):
+        d = nodes["hi"][k].astype(np.float64) - nodes["lo"][k].astype(np.float64)
+        return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
+
+    # what the collapse rule gives for a node, as a set of nodes
+    def expected_children(k):
+        ch = [k + 1, int(second[k])]
+        while len(ch) < 4:
+            inner = [c for c in ch if is_inner[c]]
+            if not inner:
+                break
+            best = max(inner, key=lambda c: (area(c), -ch.index(c)))
+            i = ch.index(best)
+            ch[i] = best + 1
+            ch.append(int(second[best]))
+        return ch
+
+    seen_leaf = np.zeros(n, np.int64)
+    todo = [(0, 0)]  # (row, node it stands for)
+    visited_rows = 0
+    while todo:
+        r, k = todo.pop()
+        visited_rows += 1
+        words, links = rows[r, :12], rows[r, 12:]
+        want = expected_children(k)
+        used = [int(l) for l in links if int(l) != NOLINK]
+        assert len(used) == len(want)
+        assert all(int(l) == NOLINK for l in links[len(used):])
+        for c, (node, link) in enumerate(zip(want, used)):
+            w = [int(x) for x in words[3 * c:3 * c + 3]]
+            q_lo = np.array([w[0] & 0xFFFF, w[0] >> 16, w[1] & 0xFFFF], np.float32)
+            q_hi = np.array([w[1] >> 16, w[2] & 0xFFFF, w[2] >> 16], np.float32)
+            lo = (q_lo.astype(np.float64) * step + base).astype(np.float32)
+            hi = (q_hi.astype(np.float64) * step + base).astype(np.float32)
+            assert np.all(lo <= nodes["lo"][node]) and np.all(hi >= nodes["hi"][node])
+            if is_inner[node]:
+                assert link & INNER and (link & ~INNER) > r
+                todo.append((link & ~INNER, node))
+            else:
+                assert link == (LEAFROW | node)   # (no surface table given: every leaf by its node)
+                seen_leaf[node] += 1
+        if len(used) < 4:
+            assert not any(is_inner[c] for c in want)
+    assert visited_rows == len(rows)
+    assert np.array_equal(seen_leaf, (~is_inner).astype(np.int64))
+
+
 def test_scene_file_round_trip(tmp_path):
     s, cam, p = scenes.build("materials")
     path = str(tmp_path / "m.ptscene")
