@@ -462,6 +462,26 @@ int pt_image_to_8bit(int device, const float* rgb, int width, int height, float 
 int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_stream);
 int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity, uint64_t* out_count);
 
+/* Diagnostics of the table that the tracing kernel for scenes in memory reads
+ * (no counterpart in the reference, whose walk, src/15/bvh.hpp:183-213, reads
+ * the nodes themselves).  A row stands for an inner node and holds up to four
+ * of its descendants -- beginning with its two children, the inner node with
+ * the largest box surface gives way to its own children until there are four
+ * or only leaves -- as 16 words: per slot three words of box corners on a
+ * 16-bit grid over the root box (lo.x | lo.y << 16, lo.z | hi.x << 16,
+ * hi.y | hi.z << 16; coordinate q of axis a stands for fmaf(q, step[a],
+ * base[a]), boxes rounded outwards), then four links: 0x80000000 | row for an
+ * inner node, 0x40000000 | node for a leaf, a surface id for a static triangle
+ * with the box of its vertices, 0x7FFFFFFF for a slot not used.  Rows are in
+ * the order of the nodes they stand for.
+ * pt_scene_get_quad_rows copies out the rows that the library made on the GPU
+ * for the installed tree (out_rows == NULL: the count only).
+ * pt_bvh_quad_rows makes them on the host from a node array (every leaf linked
+ * by its node: no surface table is consulted); it needs no GPU. */
+int pt_scene_get_quad_rows(pt_scene* scene, uint32_t* out_rows, uint64_t capacity_rows, uint64_t* out_n_rows);
+int pt_bvh_quad_rows(const pt_bvh_node* nodes, uint64_t n_nodes, uint32_t* out_rows, uint64_t capacity_rows,
+                     uint64_t* out_n_rows, float out_base[3], float out_step[3]);
+
 /* The two per-texel image passes of the reference's importer, on the GPU.
  * pt_texture_from_bytes: what TextureImage's constructor gets from stb_image
  * for an 8-bit RGB file (reference src/15/texture_image.hpp:17-33): texel =

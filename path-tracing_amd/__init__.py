@@ -7,6 +7,6 @@ from . import abi  # noqa: F401
 from .api import (  # noqa: F401
     DeviceScene, FlatScene, LoadedScene, PtError, device_count, lib, load_camera, make_animation, make_camera,
     make_params, make_transform, identity_transform, n_samples, save_camera, image_to_8bit, image_to_8bit_device,
-    texture_from_bytes, bump_to_normal_map, multi_plan, render_multi, render_multi_device, multi_last_combine, mesh_reindex, set_host_tree_builder,
+    texture_from_bytes, bump_to_normal_map, multi_plan, render_multi, render_multi_device, multi_last_combine, mesh_reindex, set_host_tree_builder, host_quad_rows,
     HIT_DTYPE, NODE_DTYPE, LIB_PATH,
 )

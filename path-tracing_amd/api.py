@@ -666,6 +666,18 @@ class DeviceScene:
         _check(lib().pt_scene_get_bvh(self.handle, nodes.ctypes.data_as(C.POINTER(abi.pt_bvh_node)), n.value, C.byref(n)))
         return nodes
 
+    def get_quad_rows(self):
+        """The rows of the four-wide walk as the device made them: (rows, 16) uint32, 12 words of boxes and 4 links
+        (empty if the scene has none)."""
+        L = lib()
+        L.pt_scene_get_quad_rows.restype = C.c_int
+        n = C.c_uint64(0)
+        _check(L.pt_scene_get_quad_rows(self.handle, None, C.c_uint64(0), C.byref(n)))
+        rows = np.zeros((n.value, 16), np.uint32)
+        if n.value:
+            _check(L.pt_scene_get_quad_rows(self.handle, rows.ctypes.data_as(C.c_void_p), C.c_uint64(n.value), C.byref(n)))
+        return rows
+
     def render(self, cam, params, out=None):
         """Host-buffer render: (height, width, 3) float32, row 0 = bottom."""
         if out is None:
@@ -734,3 +746,17 @@ class DeviceScene:
         out = (abi.pt_hit * max(n, 1))()
         _check(lib().pt_trace_rays(self.handle, n, _f(origins), _f(directions), tp, amin, amax, out))
         return np.frombuffer(out, dtype=HIT_DTYPE)[:n].copy()
+
+
+def host_quad_rows(nodes):
+    """The rows of the four-wide walk made on the host from a tree in the layout of pt_scene_desc.bvh_nodes (every
+    leaf linked by its node: no surface table is consulted).  Returns (rows (n, 16) uint32, base (3,), step (3,))."""
+    L = lib()
+    L.pt_bvh_quad_rows.restype = C.c_int
+    n = len(nodes)
+    rows = np.zeros(((n - 1) // 2 + 1, 16), np.uint32)
+    n_rows = C.c_uint64(0)
+    base, step = (C.c_float * 3)(), (C.c_float * 3)()
+    _check(L.pt_bvh_quad_rows(nodes.ctypes.data_as(C.c_void_p), C.c_uint64(n), rows.ctypes.data_as(C.c_void_p),
+                              C.c_uint64(len(rows)), C.byref(n_rows), base, step))
+    return rows[:n_rows.value], np.array(base[:], np.float32), np.array(step[:], np.float32)

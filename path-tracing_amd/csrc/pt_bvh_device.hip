@@ -1034,6 +1034,137 @@ __global__ void __launch_bounds__(kBlock) rowsFromNodesKernel(DevScene sc, const
     wide[2 * size_t(row) + 1] = make_uint4(w[4], w[5], link[0], link[1]);
 }
 
+// ---- the rows of the four-wide walk (DevScene::quad) from a finished node table ---------------------------------
+// A row stands for an inner node and holds up to four of its descendants: beginning with its two children, the inner
+// node with the largest box surface among them (the first of equals) gives way to its own two children until there
+// are four, or only leaves.  Which nodes get rows is found level by level from the root (quadMarkKernel); the rows
+// are numbered in the order of the nodes they stand for (a scan over the marks), so a row's children rows come
+// after it and a subtree's rows lie together; quadRowsKernel then writes them.
+
+PT_DEV double boxSurface(const float4* __restrict__ nodes, uint32_t k)
+{
+    const float4 a = nodes[2 * size_t(k)], b = nodes[2 * size_t(k) + 1];
+    const double dx = double(a.w) - double(a.x), dy = double(b.x) - double(a.y), dz = double(b.y) - double(a.z);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+PT_DEV uint32_t leafWordOf(const float4* __restrict__ nodes, uint32_t k) { return fbits(nodes[2 * size_t(k) + 1].w); }
+
+// (four named slots and selects instead of an indexed array: the slots stay in registers)
+struct QuadSlots {
+    uint32_t c0, c1, c2, c3, n;
+};
+
+PT_DEV QuadSlots quadSlotsOf(const float4* __restrict__ nodes, uint32_t k, uint32_t nNodes)
+{
+    QuadSlots q;
+    q.c0 = k + 1u;
+    q.c1 = leafWordOf(nodes, k) & ~kInnerBit;
+    q.c2 = q.c3 = 0u;
+    q.n = 2u;
+    for (int round = 0; round < 2; round++) {
+        int pick = -1;
+        double pickArea = -1.0;
+        uint32_t parent = 0u;
+        const uint32_t cand[4] = { q.c0, q.c1, q.c2, q.c3 };
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (uint32_t(c) < q.n && cand[c] < nNodes && (leafWordOf(nodes, cand[c]) & kInnerBit)) {
+                const double area = boxSurface(nodes, cand[c]);
+                if (area > pickArea) {
+                    pick = c;
+                    pickArea = area;
+                    parent = cand[c];
+                }
+            }
+        if (pick < 0)
+            break;
+        const uint32_t first = parent + 1u, second = leafWordOf(nodes, parent) & ~kInnerBit;
+        q.c0 = pick == 0 ? first : q.c0;
+        q.c1 = pick == 1 ? first : q.c1;
+        q.c2 = pick == 2 ? first : q.c2;
+        q.c3 = pick == 3 ? first : q.c3;
+        q.c2 = q.n == 2u ? second : q.c2;
+        q.c3 = q.n == 3u ? second : q.c3;
+        q.n++;
+    }
+    return q;
+}
+
+// one level: the nodes of `in` get rows; their inner descendants that a row holds make up the next level
+__global__ void __launch_bounds__(kBlock) quadMarkKernel(const float4* __restrict__ nodes, uint32_t nNodes, const uint32_t* __restrict__ in,
+                                                         uint32_t nIn, uint32_t* __restrict__ out, uint32_t outRoom,
+                                                         uint32_t* __restrict__ nOut, uint32_t* __restrict__ isRow)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nIn)
+        return;
+    const uint32_t k = in[i];
+    if (k >= nNodes)
+        return;
+    isRow[k] = 1u;
+    const QuadSlots q = quadSlotsOf(nodes, k, nNodes);
+    const uint32_t child[4] = { q.c0, q.c1, q.c2, q.c3 };
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (uint32_t(c) < q.n && child[c] < nNodes && (leafWordOf(nodes, child[c]) & kInnerBit)) {
+            const uint32_t at = atomicAdd(nOut, 1u);
+            if (at < outRoom)
+                out[at] = child[c];
+        }
+}
+
+__global__ void __launch_bounds__(kBlock) quadRowsKernel(DevScene sc, const float4* __restrict__ nodes, uint32_t nNodes,
+                                                         const uint32_t* __restrict__ isRow, const uint32_t* __restrict__ rowOf,
+                                                         uint32_t rowRoom, V3 base, V3 step, uint4* __restrict__ quad)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nNodes || !isRow[k])
+        return;
+    const uint32_t row = rowOf[k];
+    if (row >= rowRoom)
+        return;
+    const QuadSlots q = quadSlotsOf(nodes, k, nNodes);
+    const uint32_t child[4] = { q.c0, q.c1, q.c2, q.c3 };
+    uint32_t w[12], link[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        // a slot not used: a box nothing enters
+        w[3 * c + 0] = 0xFFFFFFFFu;
+        w[3 * c + 1] = 0x0000FFFFu;
+        w[3 * c + 2] = 0u;
+        link[c] = kQuadNoLink;
+        const uint32_t at = child[c];
+        if (uint32_t(c) < q.n && at < nNodes) {
+            const float4 b0 = nodes[2 * size_t(at)], b1 = nodes[2 * size_t(at) + 1];
+            const uint32_t qlx = gridBelow(b0.x, base.x, step.x), qly = gridBelow(b0.y, base.y, step.y), qlz = gridBelow(b0.z, base.z, step.z);
+            const uint32_t qhx = gridAbove(b0.w, base.x, step.x), qhy = gridAbove(b1.x, base.y, step.y), qhz = gridAbove(b1.y, base.z, step.z);
+            w[3 * c + 0] = qlx | (qly << 16);
+            w[3 * c + 1] = qlz | (qhx << 16);
+            w[3 * c + 2] = qhy | (qhz << 16);
+            const uint32_t l = fbits(b1.w);
+            if (l & kInnerBit) {
+                link[c] = kInnerBit | rowOf[at];
+            } else {
+                link[c] = kLeafRowBit | at;
+                if (l < sc.n_surfaces && fbits(sc.surf[3 * size_t(l)].w) == kTriStatic) {
+                    // a static triangle whose box is bit for bit that of its vertices is tested from its surface row alone
+                    const float4 r0 = sc.surf[3 * size_t(l)], r1 = sc.surf[3 * size_t(l) + 1], r2 = sc.surf[3 * size_t(l) + 2];
+                    const bool same = fbits(fminf(r0.x, fminf(r1.x, r2.x))) == fbits(b0.x) && fbits(fminf(r0.y, fminf(r1.y, r2.y))) == fbits(b0.y)
+                        && fbits(fminf(r0.z, fminf(r1.z, r2.z))) == fbits(b0.z) && fbits(fmaxf(r0.x, fmaxf(r1.x, r2.x))) == fbits(b0.w)
+                        && fbits(fmaxf(r0.y, fmaxf(r1.y, r2.y))) == fbits(b1.x) && fbits(fmaxf(r0.z, fmaxf(r1.z, r2.z))) == fbits(b1.y);
+                    if (same)
+                        link[c] = l;
+                }
+            }
+        }
+    }
+    quad[4 * size_t(row) + 0] = make_uint4(w[0], w[1], w[2], w[3]);
+    quad[4 * size_t(row) + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    quad[4 * size_t(row) + 2] = make_uint4(w[8], w[9], w[10], w[11]);
+    quad[4 * size_t(row) + 3] = make_uint4(link[0], link[1], link[2], link[3]);
+}
+
 __global__ void singleLeafKernel(const float4* __restrict__ leafBox, float4* __restrict__ nodes)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1051,6 +1182,71 @@ T* carve(char*& p, size_t count)
 }
 
 } // namespace
+
+int ptBuildQuadRowsDevice(pt_scene* scene, hipStream_t stream)
+{
+    scene->dev.quad = nullptr;
+    scene->nQuadRows = 0;
+    const uint32_t nNodes = scene->dev.n_nodes;
+    if (!scene->dev.wide || nNodes < 3 || scene->n_surfaces < 2)
+        return PT_OK;
+    const size_t rowRoom = size_t(scene->n_surfaces - 1);
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t scanBytes = 0;
+    uint32_t* nullVals = nullptr;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scanBytes, nullVals, nullVals, 0u, size_t(nNodes), rocprim::plus<uint32_t>(), stream));
+    const size_t need = 2 * pad(size_t(nNodes) * 4) + 2 * pad(rowRoom * 4) + pad(256) + pad(scanBytes);
+    if (scene->quadCapacity < need) {
+        if (scene->quadArea)
+            HIP_TRY(hipFree(scene->quadArea));
+        scene->quadArea = nullptr;
+        scene->quadCapacity = 0;
+        HIP_TRY(hipMalloc(&scene->quadArea, need));
+        scene->quadCapacity = need;
+    }
+    if (!scene->quad) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, 4 * rowRoom * sizeof(uint4)));
+        scene->owned.push_back(p);
+        scene->quad = static_cast<uint4*>(p);
+    }
+    char* p = static_cast<char*>(scene->quadArea);
+    uint32_t* isRow = carve<uint32_t>(p, size_t(nNodes));
+    uint32_t* rowOf = carve<uint32_t>(p, size_t(nNodes));
+    uint32_t* level[2] = { carve<uint32_t>(p, rowRoom), carve<uint32_t>(p, rowRoom) };
+    uint32_t* counters = carve<uint32_t>(p, 64);
+    void* scanTemp = p;
+    HIP_TRY(hipMemsetAsync(isRow, 0, size_t(nNodes) * 4, stream));
+    HIP_TRY(hipMemsetAsync(level[0], 0, 4, stream)); // the first level: the root
+    uint32_t nIn = 1, total = 0;
+    int cur = 0;
+    // (a tree is at most as deep as it has inner nodes, and every level holds at least one of them)
+    for (uint64_t guard = 0; nIn > 0 && guard < rowRoom; guard++) {
+        total += nIn;
+        if (total > rowRoom)
+            return fail(PT_ERR_DEVICE, "four-wide rows: more rows than inner nodes");
+        HIP_TRY(hipMemsetAsync(counters, 0, 4, stream));
+        hipLaunchKernelGGL(quadMarkKernel, dim3((nIn + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, scene->nodes, nNodes, level[cur], nIn,
+                           level[cur ^ 1], uint32_t(rowRoom), counters, isRow);
+        HIP_TRY(hipGetLastError());
+        uint32_t nOut = 0;
+        HIP_TRY(hipMemcpyAsync(&nOut, counters, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (nOut > rowRoom)
+            return fail(PT_ERR_DEVICE, "four-wide rows: a level with more nodes than the tree has");
+        nIn = nOut;
+        cur ^= 1;
+    }
+    HIP_TRY(rocprim::exclusive_scan(scanTemp, scanBytes, isRow, rowOf, 0u, size_t(nNodes), rocprim::plus<uint32_t>(), stream));
+    const V3 base = v3(scene->dev.qbase[0], scene->dev.qbase[1], scene->dev.qbase[2]);
+    const V3 step = v3(scene->dev.qstep[0], scene->dev.qstep[1], scene->dev.qstep[2]);
+    hipLaunchKernelGGL(quadRowsKernel, dim3((nNodes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, scene->dev, scene->nodes, nNodes, isRow, rowOf,
+                       uint32_t(rowRoom), base, step, scene->quad);
+    HIP_TRY(hipGetLastError());
+    scene->nQuadRows = total;
+    scene->dev.quad = scene->quad;
+    return PT_OK;
+}
 
 extern "C" {
 
@@ -1260,6 +1456,24 @@ int pt_scene_build_bvh_device(pt_scene* scene, float t0, float t1, void* hip_str
     }
     HIP_TRY(call.done(stream));
     return PT_OK;
+}
+
+int pt_scene_get_quad_rows(pt_scene* scene, uint32_t* out_rows, uint64_t capacity_rows, uint64_t* out_n_rows)
+try {
+    if (!scene || !out_n_rows)
+        return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+    SceneCall call(scene, nullptr);
+    HIP_TRY(call.status);
+    const uint64_t n = scene->dev.quad ? scene->nQuadRows : 0;
+    *out_n_rows = n;
+    if (!out_rows || capacity_rows < n)
+        return out_rows ? fail(PT_ERR_INVALID_ARGUMENT, "row buffer too small") : PT_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (n > 0)
+        HIP_TRY(hipMemcpy(out_rows, scene->quad, n * 4 * sizeof(uint4), hipMemcpyDeviceToHost));
+    return PT_OK;
+} catch (...) {
+    return ptint::caught();
 }
 
 int pt_scene_get_bvh(pt_scene* scene, pt_bvh_node* out_nodes, uint64_t capacity, uint64_t* out_count)

@@ -312,7 +312,7 @@ bool buildWideNodes(const pt_bvh_node* nodes, uint64_t n, const std::vector<floa
 // inner node and holds up to four of its descendants: beginning with its two children, the inner node with the
 // largest box surface among them is replaced by its own two children until there are four (or only leaves): the
 // boxes a ray is most likely to enter anyway are the ones not worth a step of their own.  Rows are numbered in
-// pre-order of the nodes they stand for, so a row's children rows come after it.  Same grid, same rounding and same
+// the order of the nodes they stand for, so a row's children rows come after it.  Same grid, same rounding and same
 // three kinds of link as the two-wide rows; a slot that is not used holds kQuadNoLink and a box nothing enters.
 // Returns false if a box cannot be put on the grid.
 bool buildQuadRows(const float4* nodes, uint64_t n, const std::vector<float4>& surf, const float base[3], const float step[3],
@@ -362,12 +362,15 @@ bool buildQuadRows(const float4* nodes, uint64_t n, const std::vector<float4>& s
         for (uint32_t c = 0; c < r.nChildren; c++)
             if (r.child[c] >= n)
                 return false;
-        rowOf[k] = uint32_t(rows.size());
         rows.push_back(r);
         for (int c = int(r.nChildren) - 1; c >= 0; c--)
             if (leafWord(r.child[c]) & kInnerBit)
                 todo.push_back(r.child[c]);
     }
+    // rows in the order of the nodes they stand for
+    std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.node < b.node; });
+    for (size_t i = 0; i < rows.size(); i++)
+        rowOf[rows[i].node] = uint32_t(i);
     // pass 2: the rows
     out.assign(4 * rows.size(), make_uint4(0, 0, 0, 0));
     for (size_t i = 0; i < rows.size(); i++) {
@@ -506,30 +509,7 @@ int launchRender(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t
 
 int ptBuildQuadRows(pt_scene* scene, hipStream_t stream)
 {
-    scene->dev.quad = nullptr;
-    // PT_QUAD_ROWS=1: trace scenes in memory with the four-wide walk
-    const char* env = std::getenv("PT_QUAD_ROWS");
-    if (!env || env[0] == '0' || !scene->dev.wide || scene->dev.n_nodes < 3)
-        return PT_OK;
-    const uint64_t n = scene->dev.n_nodes;
-    std::vector<float4> nodes(2 * n);
-    HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemcpy(nodes.data(), scene->nodes, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost));
-    std::vector<uint4> rows;
-    if (!buildQuadRows(nodes.data(), n, scene->hostSurf, scene->dev.qbase, scene->dev.qstep, rows) || rows.empty())
-        return PT_OK;
-    const size_t room = 4 * size_t(scene->n_surfaces - 1);
-    if (rows.size() > room)
-        return fail(PT_ERR_LIMIT, "four-wide rows: more rows than inner nodes");
-    if (!scene->quad) {
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, room * sizeof(uint4)));
-        scene->owned.push_back(p);
-        scene->quad = static_cast<uint4*>(p);
-    }
-    HIP_TRY(hipMemcpy(scene->quad, rows.data(), rows.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    scene->dev.quad = scene->quad;
-    return PT_OK;
+    return ptBuildQuadRowsDevice(scene, stream);
 }
 
 extern "C" {
@@ -555,6 +535,8 @@ void pt_scene_destroy(pt_scene* scene)
         (void)hipFree(p);
     if (scene->buildArea)
         (void)hipFree(scene->buildArea);
+    if (scene->quadArea)
+        (void)hipFree(scene->quadArea);
     if (scene->evStart)
         (void)hipEventDestroy(scene->evStart);
     if (scene->evStop)

@@ -202,6 +202,9 @@ struct pt_scene {
     std::vector<float4> hostSurf; // the surface table as uploaded: which leaves have the box of their vertices
     void* buildArea = nullptr; // work area of pt_scene_build_bvh_device, kept between calls (not in owned)
     size_t buildCapacity = 0;
+    void* quadArea = nullptr;  // work area of the four-wide rows' builder, likewise
+    size_t quadCapacity = 0;
+    uint32_t nQuadRows = 0;    // rows of `quad` in use
     uint64_t n_surfaces = 0;
     uint32_t nMaterials = 0, nTextures = 0, nMeshes = 0; // entries of the material-side tables (see shadeHitsKernel)
     hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -260,4 +263,5 @@ int ptWavefrontStaticSetup(int device);
 int ptWavefrontBuildWalkLinks(pt_scene* scene, float time, hipStream_t stream);
 // the rows of the four-wide walk for the tree the scene holds now (dev.nodes, dev.n_nodes, the grid of dev.wide)
 int ptBuildQuadRows(pt_scene* scene, hipStream_t stream);
+int ptBuildQuadRowsDevice(pt_scene* scene, hipStream_t stream);
 int ptWavefrontRenderStatic(pt_scene* scene, const RenderArgs& a, float* d_out, hipStream_t stream);

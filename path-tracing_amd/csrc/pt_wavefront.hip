@@ -718,6 +718,12 @@ constexpr uint32_t kOrderedBlock = PT_ORDERED_BLOCK; // threads per block of tra
 #ifndef PT_QUAD_GATE16
 #define PT_QUAD_GATE16 1
 #endif
+#ifndef PT_QUAD_STEPS_PER_VOTE
+#define PT_QUAD_STEPS_PER_VOTE 1 // (a four-wide step is twice as long: one per vote measured 1.5 % faster than two)
+#endif
+#ifndef PT_QUAD_FULL_SORT
+#define PT_QUAD_FULL_SORT 1
+#endif
 
 // one box of a row: three words on the grid (see DevScene::wide) against the ray
 PT_DEV bool gridBoxEntry(uint32_t w0, uint32_t w1, uint32_t w2, V3 base, V3 step, const Ray& ray, float cull, float& entry)
@@ -907,7 +913,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
             uint64_t walkers = __builtin_amdgcn_ballot_w64(int32_t(link) < 0);
             while (walkers != 0) {
 #pragma unroll
-                for (int rep = 0; rep < PT_ORDERED_STEPS_PER_VOTE; rep++) {
+                for (int rep = 0; rep < (WIDTH == 4 ? PT_QUAD_STEPS_PER_VOTE : PT_ORDERED_STEPS_PER_VOTE); rep++) {
                 if (WIDTH == 4 && int32_t(link) < 0) {
                     // test the boxes of the row, go to the nearest one that is hit, keep the others, the nearest on top
                     const uint32_t k = link & ~kInnerBit;
@@ -935,7 +941,9 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     nearerFirst(e2, l2, e3, l3);
                     nearerFirst(e0, l0, e2, l2);
                     nearerFirst(e1, l1, e3, l3);
+#if PT_QUAD_FULL_SORT
                     nearerFirst(e1, l1, e2, l2);
+#endif
                     // when room runs out the farthest ones are left out (the result stands if they turn out to lie
                     // beyond the limit anyway)
                     const uint32_t room = kDepth - top;
@@ -2161,17 +2169,21 @@ void launchTrace(pt_scene* sc, WavefrontBuffers& w, const Pool& pool, hipStream_
         sc->kt.begin(KernelTimes::kTraceOrdered, stream);
         // runs taken from counters by as many waves as the chip holds at once (PT_TRACE_RUNS=fixed: a wave per run)
         const uint32_t allBlocks = (slotWaves + shadowWaves) / (kOrderedBlock / 64u);
-        const bool quad = sc->dev.quad != nullptr;
+        // (PT_NO_QUAD_ROWS: the two-wide rows, one box pair per step)
+        DevScene dq = sc->dev;
+        if (std::getenv("PT_NO_QUAD_ROWS") != nullptr)
+            dq.quad = nullptr;
+        const bool quad = dq.quad != nullptr;
         // (blocks per compute unit: what registers and the stacks in LDS allow)
         static const int blocksPerUnit[2] = { residentBlocks(traceOrderedKernel<2, DYN, STATS>, kOrderedBlock),
                                               residentBlocks(traceOrderedKernel<4, DYN, STATS>, kOrderedBlock) };
         const uint32_t held = uint32_t(sc->computeUnits) * uint32_t(blocksPerUnit[quad ? 1 : 0]);
         const bool taken = !fixedRuns && held < allBlocks;
         if (quad)
-            hipLaunchKernelGGL((traceOrderedKernel<4, DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, sc->dev,
+            hipLaunchKernelGGL((traceOrderedKernel<4, DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, dq,
                                pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         else
-            hipLaunchKernelGGL((traceOrderedKernel<2, DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, sc->dev,
+            hipLaunchKernelGGL((traceOrderedKernel<2, DYN, STATS>), dim3(taken ? held : allBlocks), dim3(kOrderedBlock), 0, stream, dq,
                                pool, w.counters, parity, w.samples, shadowCap, slotWaves, taken ? 1 : 0, stats);
         sc->kt.end(stream);
         // a multiple of kRetryShards blocks: a few per sub-list, more only for large pools

@@ -63,6 +63,24 @@ def leaf_boxes(nodes, n_surfaces):
     return lo, hi
 
 
+def check_quad_rows(dev, nodes):
+    """The rows of the four-wide walk as made on the device are those the host makes from the same tree: the same
+    boxes in the same slots, the same rows behind inner slots; a leaf is linked by its node or, a static triangle
+    with the box of its vertices, by its surface."""
+    got = dev.get_quad_rows()
+    if len(got) == 0:
+        return
+    want, _, _ = pt.host_quad_rows(nodes)
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, :12], want[:, :12])
+    g, w = got[:, 12:].astype(np.int64), want[:, 12:].astype(np.int64)
+    by_node = ((w & 0xC0000000) == 0x40000000) & (w != 0x7FFFFFFF)
+    assert np.array_equal(g[~by_node], w[~by_node])
+    node = w[by_node] & 0x3FFFFFFF
+    surface = (nodes["link"][node] // 2).astype(np.int64)
+    assert np.all((g[by_node] == w[by_node]) | (g[by_node] == surface))
+
+
 def rays_for(oracle, d, cam, p, seed=1):
     rays = oracle.camera_rays(d, cam, p, math_mode=1)
     o, dirs, t = rays[:, 0:3].copy(), rays[:, 3:6].copy(), rays[:, 6].copy()
@@ -104,6 +122,7 @@ def test_device_built_tree(name, in_memory, oracle):
                 assert np.allclose(lo, rlo, rtol=1e-5, atol=1e-6) and np.allclose(hi, rhi, rtol=1e-5, atol=1e-6)
             else:
                 assert np.array_equal(lo, rlo) and np.array_equal(hi, rhi)
+            check_quad_rows(dev, nodes)
             # the device's walk over its tree = the oracle's storage-order walk over the same tree
             s.nodes = nodes
             d_dev = s.desc()

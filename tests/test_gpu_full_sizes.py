@@ -42,6 +42,12 @@ def test_two_million_triangles(oracle):
         finally:
             del os.environ["PT_TRAVERSAL"]
         assert same_bits(fast, slow)
+        os.environ["PT_NO_QUAD_ROWS"] = "1"  # the two-wide form of the nearer-child-first walk
+        try:
+            two_wide = dev.render(cam, p)
+        finally:
+            del os.environ["PT_NO_QUAD_ROWS"]
+        assert same_bits(fast, two_wide)
         assert np.isfinite(fast).all() and fast.mean() > 0.01
         tile = np.zeros_like(fast)
         dev.render(cam, pt.make_params(W, H, 2, seed=7, tile=(700, 400, 1100, 650)), out=tile)
@@ -85,6 +91,12 @@ def test_eight_million_triangles(oracle):
         finally:
             del os.environ["PT_TRAVERSAL"]
         assert same_bits(fast, slow)
+        os.environ["PT_NO_QUAD_ROWS"] = "1"  # the two-wide form of the nearer-child-first walk
+        try:
+            two_wide = dev.render(cam, p)
+        finally:
+            del os.environ["PT_NO_QUAD_ROWS"]
+        assert same_bits(fast, two_wide)
         assert np.isfinite(fast).all() and fast.mean() > 0.01
         tile = np.zeros_like(fast)
         dev.render(cam, pt.make_params(W, H, 1, seed=7, tile=(700, 400, 1100, 650)), out=tile)

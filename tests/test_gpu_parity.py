@@ -294,6 +294,10 @@ def test_walk_counters_of_the_executed_walk(cornell, oracle):
     assert c["path_rays"] + c["shadow_rays"] + root_misses == ref["rays"]
     assert 0 < c["box_rows"] < ref["node_visits"]
     assert c["retry_node_visits"] >= c["retry_rays"]
+    # (four boxes per row by default; two with PT_NO_QUAD_ROWS: more rows for the same rays)
+    two = counted(PT_NO_LDS_SCENE="1", PT_TRACE_NULL_SHADOW_RAYS="1", PT_NO_QUAD_ROWS="1")
+    assert two["path_rays"] == c["path_rays"] and two["shadow_rays"] == c["shadow_rays"]
+    assert c["box_rows"] < two["box_rows"] < ref["node_visits"]
     c = counted(PT_NO_LDS_SCENE="1")
     assert c["path_rays"] + c["shadow_rays"] + c["null_shadow_rays"] + root_misses == ref["rays"]
     # switched off: the sums stay where they are
@@ -325,7 +329,8 @@ def test_tracing_kernel_variants_of_a_small_scene(golden_dir, oracle):
                 d = scene.desc()
                 want = oracle.render_samples(C.byref(d), cam, p, math_mode=1)
             for walk in ({}, {"PT_NO_OCTANT_ROWS": "1"}, {"PT_NO_WALK_PRUNE": "1"}, {"PT_NO_WALK_PRUNE": "1", "PT_NO_OCTANT_ROWS": "1"},
-                         {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}, {"PT_NO_LDS_SCENE": "1"}):
+                         {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}, {"PT_NO_LDS_SCENE": "1"},
+                         {"PT_NO_LDS_SCENE": "1", "PT_NO_QUAD_ROWS": "1"}):
                 for rays in ({}, {"PT_TRACE_NULL_SHADOW_RAYS": "1"}, {"PT_FINISH_PATHS": "0"}, {"PT_FINISH_PATHS": "100000000"}):
                     env = dict(walk, **rays)
                     os.environ.update(env)

@@ -20,6 +20,7 @@ from hiprt import Hip
 pytestmark = pytest.mark.gpu
 
 MODES = [("default", {}), ("memory", {"PT_NO_LDS_SCENE": "1"}),
+         ("memory, two-wide rows", {"PT_NO_LDS_SCENE": "1", "PT_NO_QUAD_ROWS": "1"}),
          ("memory, storage order", {"PT_NO_LDS_SCENE": "1", "PT_TRAVERSAL": "reference"}),
          ("one lane per ray", {"PT_TRACE_RAYS": "simple"})]
 
@@ -97,7 +98,7 @@ def check(dev, desc, oracle, o, d, t=None, what="", in_plane=None):
     got = trace_all_modes(dev, o, d, t)
     model = None
     for name, hits in got.items():
-        if in_plane is not None and name in ("default", "memory"):
+        if in_plane is not None and name in ("default", "memory", "memory, two-wide rows"):
             if model is None:
                 model, _ = oracle.trace_rays_ordered(desc, o, d, t)
                 assert model[~in_plane].tobytes() == want[~in_plane].tobytes(), what

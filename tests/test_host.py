@@ -55,19 +55,6 @@ def test_bvh_structure_invariants():
             assert np.all(nodes["lo"][i] <= nodes["lo"][child]) and np.all(nodes["hi"][i] >= nodes["hi"][child])
 
 
-def _quad_rows(nodes):
-    L = pt.lib()
-    n = len(nodes)
-    rows = np.zeros(((n - 1) // 2 + 1, 16), np.uint32)
-    n_rows = C.c_uint64(0)
-    base, step = (C.c_float * 3)(), (C.c_float * 3)()
-    L.pt_bvh_quad_rows.restype = C.c_int
-    rc = L.pt_bvh_quad_rows(nodes.ctypes.data_as(C.c_void_p), C.c_uint64(n), rows.ctypes.data_as(C.c_void_p),
-                            C.c_uint64(len(rows)), C.byref(n_rows), base, step)
-    assert rc == 0, L.pt_last_error().decode()
-    return rows[:n_rows.value], np.array(base[:], np.float32), np.array(step[:], np.float32)
-
-
 @pytest.mark.parametrize("which", ["mesh", "cornell"])
 def test_four_wide_rows_cover_the_tree(which, golden_dir):
     """The rows of the four-wide walk, made on the host from the reference's tree: every leaf is reached exactly once
@@ -79,7 +66,7 @@ def test_four_wide_rows_cover_the_tree(which, golden_dir):
         s = pt.LoadedScene(os.path.join(golden_dir, "cornell.ptscene"))
     nodes = s.nodes if which == "mesh" else s.nodes()
     n = len(nodes)
-    rows, base, step = _quad_rows(nodes)
+    rows, base, step = pt.host_quad_rows(nodes)
     INNER, LEAFROW, NOLINK = 0x80000000, 0x40000000, 0x7FFFFFFF
     is_inner = nodes["link"] % 2 == 1
     second = (nodes["link"] // 2).astype(np.int64)
