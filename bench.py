@@ -347,6 +347,7 @@ def main():
         walk_per_sample = {k: walk[k] / n_s for k in walk}
 
         # per launch of the tracing step: bytes the executed walk has to move, and its vector flops
+        row_boxes = 2 if os.environ.get("PT_NO_QUAD_ROWS") else 4  # boxes per row of the walk for scenes in memory
         first_pass_rays = walk_per_sample["path_rays"] + walk_per_sample["shadow_rays"]
         per_sample = {
             "traceKernel": {
@@ -354,10 +355,14 @@ def main():
                          + 49 * walk_per_sample["path_rays"] + 64 * walk_per_sample["shadow_rays"],
                 "flops": 30 * walk_per_sample["box_rows"] + 60 * walk_per_sample["surface_tests"]},
             "traceOrderedKernel": {
-                "bytes": 32 * (walk_per_sample["box_rows"] + walk_per_sample["leaf_rows"]) + 48 * walk_per_sample["surface_tests"]
+                # a row of the nearer-child-first walk holds row_boxes boxes of 12 bytes and their 4-byte links (a slot
+                # of a row may be empty: counted all the same); a leaf that is no static triangle reads its node (32)
+                "bytes": 16 * row_boxes * walk_per_sample["box_rows"] + 32 * walk_per_sample["leaf_rows"]
+                         + 48 * walk_per_sample["surface_tests"]
                          + 49 * walk_per_sample["path_rays"] + 64 * walk_per_sample["shadow_rays"],
-                # a row of the nearer-child-first walk is two box tests (30 each) and 24 flops of decoding
-                "flops": 84 * walk_per_sample["box_rows"] + 30 * walk_per_sample["leaf_rows"] + 60 * walk_per_sample["surface_tests"]},
+                # per box a test (30) and 12 flops of decoding
+                "flops": 42 * row_boxes * walk_per_sample["box_rows"] + 30 * walk_per_sample["leaf_rows"]
+                         + 60 * walk_per_sample["surface_tests"]},
             "traceRetryKernel": {
                 "bytes": 32 * walk_per_sample["retry_node_visits"] + 48 * walk_per_sample["retry_surface_tests"]
                          + 57 * walk_per_sample["retry_rays"],
@@ -450,7 +455,7 @@ def main():
                 "dominant_kernel": hbm_line(dominant, "path state the kernel has to move by the design's own byte model / duration"),
             }
         else:
-            roofline = hbm_line(dominant, "achieved = bytes the executed walk has to move (32 per box row, 48 per surface test, ray "
+            roofline = hbm_line(dominant, "achieved = bytes the executed walk has to move (64 per row of four boxes, 48 per surface test, ray "
                                           "records in and out; counts from the instrumented kernel) / kernel duration; `traffic` = "
                                           "HBM bytes per launch from rocprofv3 counters (profiles/)")
         # the tracing kernel against its own limit, whichever kernel has the most time
