@@ -457,13 +457,17 @@ def main():
         else:
             roofline = hbm_line(dominant, "achieved = bytes the executed walk has to move (64 per row of four boxes, 48 per surface test, ray "
                                           "records in and out; counts from the instrumented kernel) / kernel duration; `traffic` = "
-                                          "HBM bytes per launch from rocprofv3 counters (profiles/)")
+                                          "HBM bytes per launch from rocprofv3 counters (profiles/); where traffic is a fraction of "
+                                          "the algorithmic bytes the rows come out of L2 and the Infinity Cache, frac can pass 1, "
+                                          "and the limit that binds is vector issue: roofline_valu")
         # the tracing kernel against its own limit, whichever kernel has the most time
         trace_name = max((n for n in kernels if n in ("traceKernel", "traceOrderedKernel")), key=lambda n: kernels[n]["ms_per_step"],
                          default=None)
         roofline_trace = None
         if trace_name and trace_name != dominant:
             roofline_trace = valu_line(trace_name) if in_lds else hbm_line(trace_name, "as `roofline`, for the tracing kernel")
+        # a scene in memory whose rows are mostly served by the caches: the dominant kernel against vector issue as well
+        roofline_valu = valu_line(dominant) if not in_lds else None
         # all kernels of one step together against both limits
         total_flops = sum(per_sample[n]["flops"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
                           for n in kernels if n in per_sample)
@@ -495,6 +499,7 @@ def main():
                     if not args.sqrt_spp and not (frames and world > 1) else None,
             "roofline": roofline,
             "roofline_trace": roofline_trace,
+            "roofline_valu": roofline_valu,
             "state_traffic": state_traffic,
             "whole_step": whole,
             "kernels": kernels,
