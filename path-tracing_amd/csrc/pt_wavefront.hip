@@ -721,9 +721,6 @@ constexpr uint32_t kOrderedBlock = PT_ORDERED_BLOCK; // threads per block of tra
 #ifndef PT_QUAD_STEPS_PER_VOTE
 #define PT_QUAD_STEPS_PER_VOTE 1 // (a four-wide step is twice as long: one per vote measured 1.5 % faster than two)
 #endif
-#ifndef PT_QUAD_FULL_SORT
-#define PT_QUAD_FULL_SORT 1
-#endif
 
 // one box of a row: three words on the grid (see DevScene::wide) against the ray
 PT_DEV bool gridBoxEntry(uint32_t w0, uint32_t w1, uint32_t w2, V3 base, V3 step, const Ray& ray, float cull, float& entry)
@@ -941,9 +938,7 @@ __global__ void __launch_bounds__(kOrderedBlock, PT_ORDERED_WAVES) traceOrderedK
                     nearerFirst(e2, l2, e3, l3);
                     nearerFirst(e0, l0, e2, l2);
                     nearerFirst(e1, l1, e3, l3);
-#if PT_QUAD_FULL_SORT
-                    nearerFirst(e1, l1, e2, l2);
-#endif
+                    nearerFirst(e1, l1, e2, l2); // (without this last exchange: 4 % slower, the kept nodes come up out of order)
                     // when room runs out the farthest ones are left out (the result stands if they turn out to lie
                     // beyond the limit anyway)
                     const uint32_t room = kDepth - top;
