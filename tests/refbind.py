@@ -339,8 +339,9 @@ class Oracle:
         return hits_to_numpy(out)
 
     def trace_rays_ordered(self, desc, origins, directions, times=None, amin=1e-4, amax=np.finfo(np.float32).max,
-                           math_mode=1, stack_limit=128):
-        """CPU model of the device's near-child-first traversal; returns (hits, stats dict)."""
+                           math_mode=1, stack_limit=128, width=2):
+        """CPU model of the device's near-child-first traversal (width = boxes tested per step: 2, or 4 as the
+        device's default walk has it); returns (hits, stats dict)."""
         origins = np.ascontiguousarray(origins, np.float32)
         directions = np.ascontiguousarray(directions, np.float32)
         n = len(origins)
@@ -350,9 +351,9 @@ class Oracle:
             tp = _f(times)
         out = (abi.pt_hit * n)()
         stats = (C.c_uint64 * 67)()
-        self._check(self.lib.oracle_trace_rays_ordered(desc, C.c_uint64(n), _f(origins), _f(directions), tp,
-                                                       C.c_float(amin), C.c_float(amax), math_mode,
-                                                       C.c_uint32(stack_limit), out, stats))
+        self._check(self.lib.oracle_trace_rays_ordered_wide(desc, C.c_uint64(n), _f(origins), _f(directions), tp,
+                                                            C.c_float(amin), C.c_float(amax), math_mode,
+                                                            C.c_uint32(stack_limit), C.c_int(width), out, stats))
         return hits_to_numpy(out), {"box_tests": int(stats[0]), "fell_back": int(stats[1]),
                                     "deepest": int(stats[2]), "depth_hist": [int(x) for x in stats[3:67]]}
 
