@@ -40,8 +40,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # HBM3E peak, GB/s
-VALU_PEAK_TFLOPS = 157.3         # FP32 vector peak with fused multiply-add, TFLOP/s
-VALU_PEAK_UNFUSED_TFLOPS = 78.6  # the same issue rate without fusing: this code is built with contraction off
+VALU_PEAK_TFLOPS = 157.3         # FP32 vector peak of the data sheet (packed fused multiply-adds), TFLOP/s
+VALU_PEAK_UNFUSED_TFLOPS = 78.6  # half of it: one plain fused multiply-add per lane where the data sheet counts a packed one
+# What one-flop instructions can reach: this code is built with contraction off (bit-reproducible results), so an
+# instruction is one flop per lane, and a plain vector instruction of a full wave measures 3.04 cycles per SIMD with
+# every SIMD busy (tools/micro/pk_rate.hip, profiles/r03_pk_rate.txt; packed ones 5-5.9: no gain per flop):
+# 256 CUs x 4 SIMDs x 64 lanes / 3.04 cycles x 2.4 GHz
+VALU_MEASURED_ONE_FLOP_TFLOPS = 256 * 4 * 64 / 3.04 * 2.4e9 / 1e12
 
 TRACE_KERNELS = ("traceKernel", "traceOrderedKernel", "traceRetryKernel")
 
@@ -414,6 +419,8 @@ def main():
                     "samples_per_launch": k.get("samples_per_launch"), "bound": "fp32-valu", "achieved": ach,
                     "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS,
                     "peak_unfused": VALU_PEAK_UNFUSED_TFLOPS, "frac_unfused": ach / VALU_PEAK_UNFUSED_TFLOPS,
+                    "measured_issue_limit_one_flop": VALU_MEASURED_ONE_FLOP_TFLOPS,
+                    "frac_of_measured_issue_limit": ach / VALU_MEASURED_ONE_FLOP_TFLOPS,
                     "flops_per_sample": per_sample.get(name, {}).get("flops"),
                     "traffic": k.get("hbm_bytes_per_launch"), "traffic_note": traffic_note}
 
@@ -437,9 +444,10 @@ def main():
             # reported under its own name.
             roofline = valu_line(dominant)
             roofline["note"] = ("scene tables (%d bytes) are held in LDS; useful flops of the reference algorithm's work over the "
-                                "kernel's duration; contraction is off for bit-reproducible results, so 78.6 TFLOP/s is the "
-                                "issue limit of this code (frac_unfused); `traffic` is path-state traffic, see state_traffic"
-                                % table_bytes)
+                                "kernel's duration; contraction is off for bit-reproducible results, so an instruction is one "
+                                "flop per lane and the issue limit of this code is the measured %.1f TFLOP/s "
+                                "(frac_of_measured_issue_limit); `traffic` is path-state traffic, see state_traffic"
+                                % (table_bytes, VALU_MEASURED_ONE_FLOP_TFLOPS))
             pmc_step = sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values() if k.get("hbm_bytes_per_launch"))
             model_step = sum(per_sample[n]["bytes"] * kernels[n]["samples_per_launch"] * kernels[n]["launches_per_step"]
                              for n in kernels if n in per_sample)
